@@ -1,0 +1,384 @@
+/*
+ * aqua_oracle.c -- CPU restatement of the reference's AquaEnv.step() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under aquaticgymenv_amd/ or gym_aqua/ may
+ * include, link, import or call this file; only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / the timed
+ * CPU baseline -- never as the product path.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * here against tests/golden/step_golden.npz and traj_golden.npz, which were
+ * produced by running the reference's own gym_aqua/envs/aqua.py in the build
+ * container (tests/golden/make_golden.py).  reset() is the exception: the
+ * reference samples with gym's Box.sample() (un-pinned third-party RNG), so the
+ * reset here is this build's own float32 specification and only its
+ * DISTRIBUTION is compared with the reference (tests/golden/reset_golden.npz):
+ * "reset parity unpinned".
+ *
+ * step(): literal float64 transcription, same operation order as the reference
+ *   gym_aqua/envs/aqua.py:135-213 (step), :128-133 (normalize_angle),
+ *   :373-390 (distances), :392-402,421-439 (predicates), :13-98 (constants).
+ * noise: the reference draws 2 uniforms from numpy's global MT19937
+ *   (aqua.py:188).  That stream cannot exist on a GPU; here the two draws are
+ *   either INJECTED (noise_u, in [-1,1), multiplied by sigma) or taken from
+ *   Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123 v1.09 known
+ *   answers are checked in tests/test_oracle_golden.py).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ Philox */
+static inline void philox4x32_10(uint32_t k0, uint32_t k1, const uint32_t ctr[4], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void aqua_oracle_philox(uint32_t k0, uint32_t k1, const uint32_t ctr[4], uint32_t out[4])
+{
+    philox4x32_10(k0, k1, ctr, out);
+}
+
+/* stream ids of this build's RNG specification (DESIGN.md "RNG") */
+enum { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3 };
+
+static inline void aqua_draw(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, uint32_t attempt,
+                             uint32_t out[4])
+{
+    uint32_t ctr[4];
+    ctr[0] = (uint32_t)env;
+    ctr[1] = (uint32_t)(env >> 32);
+    ctr[2] = (uint32_t)tick;
+    ctr[3] = ((uint32_t)(tick >> 32) & 0xFFFFu) | ((attempt & 0xFFu) << 16) | (stream << 24);
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), ctr, out);
+}
+
+/* 24-bit uniforms: exactly representable in float32 and float64 */
+static inline double u_pm1(uint32_t r) { return (double)(r >> 8) * 0x1p-23 - 1.0; }   /* [-1, 1) */
+static inline float u01f(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }            /* [0, 1)  */
+
+void aqua_oracle_step_noise(uint64_t seed, uint64_t env, uint64_t tick, double out_u[2], uint32_t raw[4])
+{
+    aqua_draw(seed, env, tick, STREAM_STEP, 0, raw);
+    out_u[0] = u_pm1(raw[0]);
+    out_u[1] = u_pm1(raw[1]);
+}
+
+/* ------------------------------------------------------- geometry, float64 */
+/* aqua.py:373-377 */
+static double dist_circle_circle(double ax, double ay, double ar, double bx, double by, double br)
+{
+    double dx = ax - bx, dy = ay - by;
+    double centers = sqrt(dx * dx + dy * dy);
+    double total = ar + br;
+    return centers - total;
+}
+
+static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* aqua.py:379-390 */
+static double dist_rect_circle(double rx, double ry, double rw, double rh, double cx, double cy, double cr)
+{
+    double l = rx - rw / 2, r = rx + rw / 2, b = ry - rh / 2, t = ry + rh / 2;
+    double dx = cx - clipd(cx, l, r);
+    double dy = cy - clipd(cy, b, t);
+    return sqrt(dx * dx + dy * dy) - cr;
+}
+
+#define BOAT_RADIUS 2.5
+#define GOAL_RADIUS 2.5
+#define AXLE 2.5
+#define WORLD 100.0
+#define THRUST_EPS 1e-8
+#define TIME_LIMIT 1000
+
+/* obstacle rows: cx, cy, kind (0 circle, 1 rectangle), a (radius | width), b (unused | height) */
+static double obstacle_distance(const double* o, double px, double py, double pr)
+{
+    if (o[2] == 0.0)
+        return dist_circle_circle(o[0], o[1], o[3], px, py, pr);
+    return dist_rect_circle(o[0], o[1], o[3], o[4], px, py, pr);
+}
+
+/* aqua.py:429-439 (first hit wins; the result is an OR so order does not matter) */
+static int collided_obstacle(int K, const double* obst, double px, double py, double pr, double* min_dist)
+{
+    int hit = 0;
+    double m = INFINITY;
+    for (int k = 0; k < K; ++k) {
+        double d = obstacle_distance(obst + 5 * k, px, py, pr);
+        if (d < m) m = d;
+        if (d <= 0) hit = 1;
+    }
+    if (min_dist) *min_dist = m;
+    return hit;
+}
+
+/* aqua.py:424-427: strict comparisons */
+static int collided_border(double px, double py, double pr)
+{
+    return (px - pr < 0.0) || (py - pr < 0.0) || (px + pr > WORLD) || (py + pr > WORLD);
+}
+
+/* aqua.py:128-133 with range [-pi, pi] */
+static double wrap_angle(double value)
+{
+    double start = -M_PI, end = M_PI;
+    double width = end - start;
+    double off = value - start;
+    return (off - (floor(off / width) * width)) + start;
+}
+
+/* one env, one step.  s = x, y, theta, gx, gy, wx, wy (updated in place). */
+static void step_one(int K, const double* obst, int waves, double s[7], int32_t* time, double vl, double vr,
+                     const double u[2], double* reward, uint8_t* term, double margins[3])
+{
+    const double wave_lo = -0.05 * waves, wave_hi = 0.05 * waves, sigma = 0.001 * waves;
+    double px = s[0], py = s[1], th = s[2];
+    const double gx = s[3], gy = s[4];
+    const double prev_x = px, prev_y = py;
+    *time += 1;                                                          /* aqua.py:141 */
+
+    double diff = vr - vl;                                               /* aqua.py:159 */
+    diff = copysign(fmax(fabs(diff), THRUST_EPS), diff);                 /* aqua.py:160 */
+    double r = AXLE / 2 * (vr + vl) / diff;                              /* aqua.py:166 */
+    double w = diff / AXLE;                                              /* aqua.py:168 */
+    double angle = M_PI / 2 + th;                                        /* aqua.py:173 */
+    double icc_x = px + r * (-sin(angle));                               /* aqua.py:174 */
+    double icc_y = py + r * cos(angle);
+    double c = cos(w), sn = sin(w);                                      /* aqua.py:176 (tau = 1) */
+    double qx = px - icc_x, qy = py - icc_y;
+    double nx = (c * qx + (-sn) * qy) + icc_x + s[5];                    /* aqua.py:180-181 */
+    double ny = (sn * qx + c * qy) + icc_y + s[6];
+    px = nx; py = ny;
+    th = wrap_angle(th + w);                                             /* aqua.py:183 */
+
+    s[5] = clipd(s[5] + u[0] * sigma, wave_lo, wave_hi);                 /* aqua.py:188-191 */
+    s[6] = clipd(s[6] + u[1] * sigma, wave_lo, wave_hi);
+
+    double m_obst;
+    int hit_o = collided_obstacle(K, obst, px, py, BOAT_RADIUS, &m_obst);
+    int hit_b = collided_border(px, py, BOAT_RADIUS);
+    double d_cur = dist_circle_circle(gx, gy, GOAL_RADIUS, px, py, BOAT_RADIUS);       /* aqua.py:392-402 */
+    double d_prev = dist_circle_circle(gx, gy, GOAL_RADIUS, prev_x, prev_y, BOAT_RADIUS);
+    if (hit_o || hit_b) { *term = 1; *reward = -10.0; }                  /* aqua.py:200-202 */
+    else if (*time > TIME_LIMIT) { *term = 2; *reward = -10.0; }         /* aqua.py:203-205 */
+    else if (d_cur <= 0) { *term = 3; *reward = 10.0; }                  /* aqua.py:206-208 */
+    else { *term = 0; *reward = (d_prev - d_cur) * 0.7; }                /* aqua.py:89-90,210 */
+    s[0] = px; s[1] = py; s[2] = th;
+    if (margins) {
+        double bl = fmin(px - BOAT_RADIUS, py - BOAT_RADIUS);            /* aqua.py:404-407 */
+        double tr = fmin(WORLD - (px + BOAT_RADIUS), WORLD - (py + BOAT_RADIUS));
+        margins[0] = fmin(bl, tr);
+        margins[1] = m_obst;
+        margins[2] = d_cur;
+    }
+}
+
+/* action decode: aqua.py:33-43,154 (discrete) and aqua.py:144-151 (continuous clip) */
+static void decode_action(int kind, const void* action, int64_t i, int64_t n, double* vl, double* vr)
+{
+    static const double tab[3][2] = {{0.2, 0.5}, {0.5, 0.2}, {0.5, 0.5}};
+    if (kind == 3) {
+        const float* a = (const float*)action;
+        double l = (double)a[i], r = (double)a[n + i];
+        int inside = (l >= 0.2 && l <= 0.5 && r >= 0.2 && r <= 0.5);
+        if (!inside) { l = clipd(l, 0.2, 0.5); r = clipd(r, 0.2, 0.5); }
+        *vl = l; *vr = r;
+        return;
+    }
+    int64_t a;
+    if (kind == 0) a = ((const uint8_t*)action)[i];
+    else if (kind == 1) a = ((const int32_t*)action)[i];
+    else a = ((const int64_t*)action)[i];
+    if (a < 0) a += 3;                    /* Python list index wrap-around */
+    if (a < 0) a = 0;
+    if (a > 2) a = 2;                     /* the reference raises IndexError; the batched build clamps */
+    *vl = tab[a][0]; *vr = tab[a][1];
+}
+
+/*
+ * Batched step, float64 state, SoA [7][n].  noise_u == NULL -> Philox(seed, env_offset + i, tick).
+ * margins (optional) [3][n]: border, nearest obstacle, goal distance (all "<= 0 / < 0 means hit").
+ */
+void aqua_oracle_step(int64_t n, int K, const double* obst, int waves, double* state, int32_t* time,
+                      int action_kind, const void* action, const double* noise_u, uint64_t seed, uint64_t tick,
+                      int64_t env_offset, double* reward, uint8_t* term, double* margins)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double s[7], u[2], m[3], vl, vr;
+        for (int j = 0; j < 7; ++j) s[j] = state[j * n + i];
+        if (noise_u) { u[0] = noise_u[i]; u[1] = noise_u[n + i]; }
+        else { uint32_t raw[4]; aqua_oracle_step_noise(seed, (uint64_t)(env_offset + i), tick, u, raw); }
+        decode_action(action_kind, action, i, n, &vl, &vr);
+        step_one(K, obst, waves, s, &time[i], vl, vr, u, &reward[i], &term[i], margins ? m : NULL);
+        for (int j = 0; j < 7; ++j) state[j * n + i] = s[j];
+        if (margins) { margins[i] = m[0]; margins[n + i] = m[1]; margins[2 * n + i] = m[2]; }
+    }
+}
+
+/* ----------------------------------------------------------- reset, float32 */
+/*
+ * This build's reset specification (reference behaviour: aqua.py:100-126,442-455 -- rejection
+ * sampling of a goal clear of border+obstacles, then of a boat pose clear of goal, border and
+ * obstacles, then a wave in the wave box; time = 0).  All arithmetic is float32 with every
+ * rounding explicit (fmaf or a single operation per statement) so a device implementation can be
+ * bit-identical.  Positions are drawn directly in [2.5, 97.5): rejecting border hits of a draw in
+ * [0, 100] gives the same distribution.  After 64 rejected attempts the fixed pose of
+ * aqua.py:107,117 is used.
+ */
+typedef struct { float lox, loy, hix, hiy, r2; } ObstF;
+
+static void obst_to_f32(int K, const double* obst, double other_radius, ObstF* t)
+{
+    for (int k = 0; k < K; ++k) {
+        const double* o = obst + 5 * k;
+        double hx = 0, hy = 0, rs = other_radius;
+        if (o[2] == 0.0) rs += o[3]; else { hx = o[3] / 2; hy = o[4] / 2; }
+        t[k].lox = (float)(o[0] - hx); t[k].hix = (float)(o[0] + hx);
+        t[k].loy = (float)(o[1] - hy); t[k].hiy = (float)(o[1] + hy);
+        t[k].r2 = (float)(rs * rs);
+    }
+}
+
+static int hit_f32(int K, const ObstF* t, float px, float py)
+{
+    int hit = 0;
+    for (int k = 0; k < K; ++k) {
+        float qx = fminf(fmaxf(px, t[k].lox), t[k].hix);
+        float qy = fminf(fmaxf(py, t[k].loy), t[k].hiy);
+        float dx = px - qx, dy = py - qy;
+        float dy2 = dy * dy;
+        float d2 = fmaf(dx, dx, dy2);
+        hit |= (d2 <= t[k].r2);
+    }
+    return hit;
+}
+
+#define RESET_TRIES 64
+#define KMAX 64
+
+void aqua_oracle_reset(int64_t n, int K, const double* obst, int waves, int random_boat, int random_goal,
+                       uint64_t seed, uint64_t tick, int64_t env_offset, const uint8_t* mask, float* state,
+                       int64_t ld, int32_t* time)
+{
+    ObstF t[KMAX];
+    if (K > KMAX) K = KMAX;
+    obst_to_f32(K, obst, 2.5, t);           /* goal radius == boat radius == 2.5 (aqua.py:72,75) */
+    const float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+#pragma omp parallel for schedule(static) if (n > 4096)
+    for (int64_t i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        uint64_t env = (uint64_t)(env_offset + i);
+        uint32_t r[4];
+        float gx = 25.0f, gy = 80.0f;
+        if (random_goal) {
+            for (uint32_t a = 0; a < RESET_TRIES; ++a) {
+                aqua_draw(seed, env, tick, STREAM_GOAL, a, r);
+                float cx = fmaf(95.0f, u01f(r[0]), 2.5f);
+                float cy = fmaf(95.0f, u01f(r[1]), 2.5f);
+                if (!hit_f32(K, t, cx, cy)) { gx = cx; gy = cy; break; }
+            }
+        }
+        float bx = 85.0f, by = 45.0f, bt = 0.0f;
+        if (random_boat) {
+            for (uint32_t a = 0; a < RESET_TRIES; ++a) {
+                aqua_draw(seed, env, tick, STREAM_BOAT, a, r);
+                float cx = fmaf(95.0f, u01f(r[0]), 2.5f);
+                float cy = fmaf(95.0f, u01f(r[1]), 2.5f);
+                float ct = fmaf(TWO_PI_F, u01f(r[2]), -PI_F);
+                float ex = gx - cx, ey = gy - cy;
+                float ey2 = ey * ey;
+                float g2 = fmaf(ex, ex, ey2);
+                if (g2 <= 25.0f) continue;                       /* on the goal: aqua.py:112 */
+                if (hit_f32(K, t, cx, cy)) continue;
+                bx = cx; by = cy; bt = ct;
+                break;
+            }
+        }
+        aqua_draw(seed, env, tick, STREAM_WAVE, 0, r);
+        float W = 0.05f * (float)waves;
+        float wx = W * (float)u_pm1(r[0]);
+        float wy = W * (float)u_pm1(r[1]);
+        state[0 * ld + i] = bx; state[1 * ld + i] = by; state[2 * ld + i] = bt;
+        state[3 * ld + i] = gx; state[4 * ld + i] = gy;
+        state[5 * ld + i] = wx; state[6 * ld + i] = wy;
+        time[i] = 0;
+    }
+}
+
+/* ------------------------------------------------- float32-state rollout */
+/*
+ * The batched build stores its state in float32.  This drives step_one() from float32 storage
+ * (state widened exactly to float64, result rounded to float32) with Philox noise, on-spec action
+ * sampling and auto-reset; it is the CPU baseline timed by bench.py and the multi-step checker.
+ * actions == NULL -> actions are sampled from the step draw (raw[2], raw[3]) as the device
+ * rollout does.  Returns the number of finished episodes.
+ */
+int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves, int continuous, float* state,
+                                int64_t ld, int32_t* time, int64_t steps, const void* actions, int action_kind,
+                                uint64_t seed, uint64_t tick0, int64_t env_offset, int auto_reset, float* reward,
+                                uint8_t* term, int64_t* term_counts)
+{
+    int64_t episodes = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int64_t t = 0; t < steps; ++t) {
+        uint64_t tick = tick0 + (uint64_t)t;
+#pragma omp parallel for schedule(static) reduction(+ : episodes, c1, c2, c3)
+        for (int64_t i = 0; i < n; ++i) {
+            double s[7], u[2], vl, vr, rew;
+            uint32_t raw[4];
+            uint8_t code;
+            for (int j = 0; j < 7; ++j) s[j] = (double)state[j * ld + i];
+            aqua_oracle_step_noise(seed, (uint64_t)(env_offset + i), tick, u, raw);
+            if (actions) {
+                size_t esz = action_kind == 0 ? 1 : action_kind == 1 ? 4 : action_kind == 2 ? 8 : 8;
+                const char* base = (const char*)actions + (size_t)t * (size_t)n * esz;
+                decode_action(action_kind, base, i, n, &vl, &vr);
+            } else if (continuous) {
+                float fl = fmaf(0.3f, u01f(raw[2]), 0.2f), fr = fmaf(0.3f, u01f(raw[3]), 0.2f);
+                vl = clipd((double)fl, 0.2, 0.5); vr = clipd((double)fr, 0.2, 0.5);
+            } else {
+                static const double tab[3][2] = {{0.2, 0.5}, {0.5, 0.2}, {0.5, 0.5}};
+                uint32_t a = (uint32_t)(((uint64_t)(raw[2] >> 8) * 3u) >> 24);
+                vl = tab[a][0]; vr = tab[a][1];
+            }
+            step_one(K, obst, waves, s, &time[i], vl, vr, u, &rew, &code, NULL);
+            for (int j = 0; j < 7; ++j) state[j * ld + i] = (float)s[j];
+            reward[i] = (float)rew;
+            term[i] = code;
+            if (code) { episodes++; c1 += code == 1; c2 += code == 2; c3 += code == 3; }
+        }
+        if (auto_reset)
+            aqua_oracle_reset(n, K, obst, waves, 1, 1, seed, tick, env_offset, term, state, ld, time);
+    }
+    if (term_counts) { term_counts[0] = c1; term_counts[1] = c2; term_counts[2] = c3; }
+    return episodes;
+}
+
+int aqua_oracle_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,483 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY where /root/reference exists (the build container).  It executes the
+reference's own, unmodified ``gym_aqua/envs/aqua.py`` (``AquaEnv.step`` at
+aqua.py:135-213, helpers at aqua.py:373-455, ``reset`` at aqua.py:100-126) and
+records inputs and outputs as plain arrays.  Nothing of the reference's text is
+stored: the .npz files hold numbers only.
+
+``gym`` is not installed in this image.  aqua.py uses three names from it
+(``gym.Env`` as a base class, ``gym.spaces.Box`` and ``gym.spaces.Discrete``);
+an in-memory module with those three names is registered before loading.  The
+stand-in owns no arithmetic of ``step()``: Box only stores the ``low``/``high``
+arrays that aqua.py itself passes in (aqua.py:46-53) and answers ``contains``.
+Its ``sample()`` (used by ``reset()`` only) is numpy ``uniform(low, high)`` from a
+per-space RandomState, which is what gym 0.17/0.18 did for bounded boxes.
+
+How the wave noise is made reproducible: aqua.py:188 draws from the global numpy
+RNG.  We ``np.random.seed(s)`` before the step and replay the same two draws
+from ``np.random.RandomState(s)`` to store them as ``noise_u = draw / sigma`` in
+[-1, 1).  The env's internal state is overwritten with float32-representable
+values before every recorded step (teacher forcing), so a float32 device
+implementation can start from bit-identical inputs.
+
+Usage:  python tests/golden/make_golden.py [--time]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+REF = "/root/reference/gym_aqua/envs/aqua.py"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# loader
+# --------------------------------------------------------------------------
+def load_reference():
+    gym = types.ModuleType("gym")
+    spaces = types.ModuleType("gym.spaces")
+
+    class Env(object):
+        pass
+
+    class Box(object):
+        def __init__(self, low, high, shape=None, dtype=np.float64):
+            if shape is not None:
+                low = np.full(shape, low, dtype=dtype)
+                high = np.full(shape, high, dtype=dtype)
+            self.low = np.asarray(low, dtype=dtype)
+            self.high = np.asarray(high, dtype=dtype)
+            self.shape = self.low.shape
+            self.dtype = dtype
+            self._rng = np.random.RandomState(12345)
+
+        def sample(self):
+            return self._rng.uniform(self.low, self.high)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    class Discrete(object):
+        def __init__(self, n):
+            self.n = n
+            self._rng = np.random.RandomState(12345)
+
+        def sample(self):
+            return int(self._rng.randint(self.n))
+
+    gym.Env = Env
+    spaces.Box = Box
+    spaces.Discrete = Discrete
+    gym.spaces = spaces
+    sys.modules["gym"] = gym
+    sys.modules["gym.spaces"] = spaces
+    spec = importlib.util.spec_from_file_location("aqua_ref", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# --------------------------------------------------------------------------
+# configurations (obstacle sets are data: centre, kind, size)
+# --------------------------------------------------------------------------
+def obst_list(rows):
+    out = []
+    for cx, cy, kind, a, b in rows:
+        if kind == 0:
+            out.append((np.array([cx, cy]), "c", a))
+        else:
+            out.append((np.array([cx, cy]), "r", (a, b)))
+    return out
+
+
+# rows: cx, cy, kind (0 circle, 1 rect), a (radius | width), b (0 | height)
+SET_NONE = []
+SET_DIFFICULT = [(15, 70, 0, 5, 0), (25, 40, 1, 10, 10), (40, 80, 1, 10, 10),
+                 (55, 20, 0, 10, 0), (60, 55, 1, 20, 20), (85, 75, 0, 5, 0)]
+# 4 circles + 4 rectangles used by the bench configs
+SET_BENCH8 = [(15, 75, 0, 5, 0), (20, 35, 0, 10, 0), (85, 20, 0, 10, 0), (85, 75, 0, 5, 0),
+              (65, 85, 1, 5, 5), (25, 40, 1, 10, 10), (40, 80, 1, 10, 10), (60, 55, 1, 20, 20)]
+# non-integer geometry, to exercise float obstacle tables
+SET_FRACT = [(33.25, 61.5, 0, 3.75, 0), (70.125, 30.5, 1, 7.5, 12.25), (50.5, 50.5, 1, 0.5, 30.0)]
+
+# name, obstacles argument (True -> the reference builds its own default list), continuous, waves
+CONFIGS = [
+    ("none_disc_waves", SET_NONE, False, True),
+    ("default5_disc_waves", True, False, True),
+    ("difficult6_disc_waves", SET_DIFFICULT, False, True),
+    ("bench8_disc_waves", SET_BENCH8, False, True),
+    ("bench8_cont_waves", SET_BENCH8, True, True),
+    ("none_cont_nowaves", SET_NONE, True, False),
+    ("default5_disc_nowaves", True, False, False),
+    ("fract3_cont_waves", SET_FRACT, True, True),
+]
+
+
+def make_env(mod, cfg):
+    _, obst, continuous, waves = cfg
+    cls = mod.AquaContinuousEnv if continuous else mod.AquaEnv
+    arg = obst if isinstance(obst, bool) else obst_list(obst)
+    env = cls(obstacles=arg, waves=waves)
+    return env
+
+
+def obstacle_table(env):
+    rows = []
+    for pos, kind, dims in env.obstacles:
+        if kind == "c":
+            rows.append([float(pos[0]), float(pos[1]), 0.0, float(dims), 0.0])
+        else:
+            rows.append([float(pos[0]), float(pos[1]), 1.0, float(dims[0]), float(dims[1])])
+    return np.asarray(rows, dtype=np.float64).reshape(-1, 5)
+
+
+def f32r(x):
+    """round to float32, return as float64 (float32-representable)."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# one recorded step
+# --------------------------------------------------------------------------
+def record_step(env, continuous, state7, t_in, act_i, act_c, seed):
+    sigma = env.wave_speed_variance
+    env._boat_state = np.array(state7[0:3], dtype=np.float64)
+    env._goal_state = np.array(state7[3:5], dtype=np.float64)
+    env._wave_speed = np.array(state7[5:7], dtype=np.float64)
+    env._boat_prev_state = None
+    env.time = int(t_in)
+    np.random.seed(seed)
+    draws = np.random.RandomState(seed).uniform(-sigma, sigma, 2)
+    noise_u = draws / sigma if sigma > 0 else np.zeros(2)
+    if continuous:
+        a = np.array(act_c, dtype=np.float32)  # scripts pass float32/float64 arrays; cast at aqua.py:138
+        # silence the reference's out-of-range print (aqua.py:146)
+        stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+        try:
+            obs, rew, done, info = env.step(a)
+        finally:
+            sys.stdout.close()
+            sys.stdout = stdout
+    else:
+        obs, rew, done, info = env.step(int(act_i))
+    term = 0
+    if info["Termination.collided"]:
+        term = 1
+    elif info["Termination.time"]:
+        term = 2
+    elif info["Termination.success"]:
+        term = 3
+    assert bool(done) == (term != 0)
+    m_border = env._distance_boat_from_nearest_border()
+    m_obst = env._distance_boat_from_nearest_obstacle()
+    m_goal = env._distance_boat_from_goal()
+    return dict(pose=np.array(obs[0:3]), goal_out=np.array(obs[3:5]), reward=float(rew), term=term,
+                wave_out=np.array(env._wave_speed), thrust_total=float(env._thrust_total),
+                noise_u=noise_u, m_border=float(m_border), m_obst=float(m_obst), m_goal=float(m_goal),
+                time_out=int(env.time), reward_is_int=isinstance(rew, int))
+
+
+def displacement(theta, vl, vr):
+    """chord-form displacement in float64 (test scaffolding, used only to place poses near thresholds)."""
+    d = vr - vl
+    d = np.copysign(max(abs(d), 1e-8), d)
+    w = d / 2.5
+    h = 0.5 * w
+    v = 0.5 * (vl + vr)
+    chord = v * np.sin(h) / h
+    return -chord * np.sin(theta + h), chord * np.cos(theta + h), w
+
+
+DISC = [(0.2, 0.5), (0.5, 0.2), (0.5, 0.5)]
+
+
+def gen_rows(mod, rng):
+    rows = []
+    tables = []
+    for ci, cfg in enumerate(CONFIGS):
+        name, _, continuous, waves = cfg
+        env = make_env(mod, cfg)
+        env.reset()
+        tab = obstacle_table(env)
+        tables.append(tab)
+        W = 0.05 * int(waves)
+        n_rand, n_near = 420, 420
+
+        def rand_action():
+            ai = int(rng.randint(3))
+            if continuous:
+                kind = rng.randint(10)
+                if kind == 0:      # equal thrusts -> epsilon branch (aqua.py:160)
+                    v = rng.uniform(0.2, 0.5)
+                    ac = (v, v)
+                elif kind == 1:    # out of range -> clip branch (aqua.py:145-150)
+                    ac = (rng.uniform(-0.2, 0.9), rng.uniform(-0.2, 0.9))
+                elif kind == 2:    # nearly equal
+                    v = rng.uniform(0.2, 0.5)
+                    ac = (v, v * (1 + rng.uniform(-1e-6, 1e-6)))
+                else:
+                    ac = (rng.uniform(0.2, 0.5), rng.uniform(0.2, 0.5))
+                ac = tuple(f32r(ac))
+                vl, vr = np.clip(ac, 0.2, 0.5)
+            else:
+                ac = (0.0, 0.0)
+                vl, vr = DISC[ai]
+            return ai, ac, vl, vr
+
+        def rand_time():
+            k = rng.randint(8)
+            return int([999, 1000, 1001, 0, 5][k]) if k < 5 else int(rng.randint(0, 1000))
+
+        # ---- uniformly random poses (some outside the border, some inside obstacles)
+        for _ in range(n_rand):
+            ai, ac, vl, vr = rand_action()
+            st = np.concatenate([rng.uniform(-1, 101, 2), rng.uniform(-np.pi, np.pi, 1),
+                                 rng.uniform(2.5, 97.5, 2), rng.uniform(-W, W, 2) if W else np.zeros(2)])
+            rows.append((ci, f32r(st), rand_time(), ai, ac))
+
+        # ---- poses whose POST-move position sits at a chosen small margin from a threshold
+        deltas = np.array([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 5e-5, -5e-5, 1e-4, -1e-4,
+                           3e-4, -3e-4, 1e-3, -1e-3, 1e-2, -1e-2])
+        for k in range(n_near):
+            ai, ac, vl, vr = rand_action()
+            theta = rng.uniform(-np.pi, np.pi)
+            wave = rng.uniform(-W, W, 2) if W else np.zeros(2)
+            wave = f32r(wave)
+            theta = float(f32r(theta))
+            dx, dy, _ = displacement(theta, vl, vr)
+            delta = deltas[k % len(deltas)]
+            goal = rng.uniform(2.5, 97.5, 2)
+            what = rng.randint(3) if len(tab) else rng.randint(2)
+            if what == 0:      # border: post-move x or y at 2.5+delta / 97.5-delta
+                p = rng.uniform(10, 90, 2)
+                axis = rng.randint(2)
+                p[axis] = (2.5 + delta) if rng.randint(2) else (97.5 - delta)
+            elif what == 1:    # goal: post-move distance 5 + delta
+                p = rng.uniform(15, 85, 2)
+                ang = rng.uniform(0, 2 * np.pi)
+                goal = p + (5.0 + delta) * np.array([np.cos(ang), np.sin(ang)])
+            else:              # obstacle surface + delta
+                o = tab[rng.randint(len(tab))]
+                ang = rng.uniform(0, 2 * np.pi)
+                if o[2] == 0:
+                    p = o[0:2] + (o[3] + 2.5 + delta) * np.array([np.cos(ang), np.sin(ang)])
+                else:
+                    hx, hy = o[3] / 2, o[4] / 2
+                    side = rng.randint(5)
+                    if side == 0:
+                        p = np.array([o[0] + hx + 2.5 + delta, o[1] + rng.uniform(-hy, hy)])
+                    elif side == 1:
+                        p = np.array([o[0] - hx - 2.5 - delta, o[1] + rng.uniform(-hy, hy)])
+                    elif side == 2:
+                        p = np.array([o[0] + rng.uniform(-hx, hx), o[1] + hy + 2.5 + delta])
+                    elif side == 3:
+                        p = np.array([o[0] + rng.uniform(-hx, hx), o[1] - hy - 2.5 - delta])
+                    else:      # round corner
+                        a4 = rng.uniform(0, np.pi / 2)
+                        p = np.array([o[0] + hx, o[1] + hy]) + (2.5 + delta) * np.array([np.cos(a4), np.sin(a4)])
+            pre = p - np.array([dx, dy]) - wave
+            st = np.concatenate([pre, [theta], goal, wave])
+            rows.append((ci, f32r(st), int(rng.randint(0, 990)), ai, ac))
+    return rows, tables
+
+
+def hand_rows():
+    """Known-answer cases listed in SURVEY.md 8(c); config indices refer to CONFIGS."""
+    R = []
+    z = (0.0, 0.0)
+    NW, DNW = 5, 6          # none_cont_nowaves, default5_disc_nowaves
+    # straight move, theta = 0, waves off (discrete, default obstacles are far away)
+    R.append((DNW, [50, 50, 0, 50, 90, 0, 0], 0, 2, z))
+    # border conventions are strict (aqua.py:424-427): x' == 2.5 is free, just below collides
+    for x in (2.5, np.float32(2.4999998), 97.5, np.float32(97.50001)):
+        R.append((DNW, [x, 50, 0, 50, 90, 0, 0], 0, 2, z))
+    for y in (2.0, np.float32(1.9999999), 97.0, np.float32(97.00001)):   # y' = y + 0.5
+        R.append((DNW, [50, y, 0, 10, 10, 0, 0], 0, 2, z))
+    # circle (15,75) r5 tangent from above after the move: y' = 82.5 -> distance 0 -> collided (<=)
+    R.append((DNW, [15, 82.0, 0, 50, 10, 0, 0], 0, 2, z))
+    R.append((DNW, [15, np.float32(82.00001), 0, 50, 10, 0, 0], 0, 2, z))
+    # rectangle (65,85) 5x5: centre inside, edge touch at x'=70 (heading -pi/2 moves +x)
+    R.append((DNW, [65, 84.5, 0, 50, 10, 0, 0], 0, 2, z))
+    R.append((DNW, [69.5, 85, -np.pi / 2, 10, 10, 0, 0], 0, 2, z))
+    R.append((DNW, [70.5, 90.0, 0, 10, 10, 0, 0], 0, 2, z))     # corner region, y' = 90.5
+    # collision and goal together -> collision wins (aqua.py:200)
+    R.append((DNW, [15, 82.0, 0, 15, 84, 0, 0], 0, 2, z))
+    # time limit: 1000 -> 1001 with goal reached -> time wins; 999 -> 1000 with goal -> success
+    R.append((DNW, [50, 50, 0, 50, 52, 0, 0], 1000, 2, z))
+    R.append((DNW, [50, 50, 0, 50, 52, 0, 0], 999, 2, z))
+    R.append((DNW, [50, 50, 0, 50, 90, 0, 0], 1000, 2, z))
+    R.append((DNW, [50, 50, 0, 50, 90, 0, 0], 5000, 0, z))      # stepping long after done
+    # angle wrap
+    R.append((DNW, [50, 50, np.pi - 0.05, 50, 90, 0, 0], 0, 0, z))
+    R.append((DNW, [50, 50, -np.pi + 0.05, 50, 90, 0, 0], 0, 1, z))
+    R.append((DNW, [50, 50, np.float32(np.pi), 50, 90, 0, 0], 0, 2, z))
+    R.append((DNW, [50, 50, np.float32(-np.pi), 50, 90, 0, 0], 0, 2, z))
+    # all three discrete actions from one pose
+    for a in (0, 1, 2):
+        R.append((DNW, [40, 60, 1.0, 70, 20, 0, 0], 7, a, z))
+    # continuous: equal thrusts (epsilon branch), out-of-range (clip), float32 [0.3, 0.3]
+    R.append((NW, [50, 50, 0.5, 20, 20, 0, 0], 0, 0, (0.3, 0.3)))
+    R.append((NW, [50, 50, 0.5, 20, 20, 0, 0], 0, 0, (0.2, 0.5)))
+    R.append((NW, [50, 50, 0.5, 20, 20, 0, 0], 0, 0, (0.9, -0.4)))
+    R.append((NW, [50, 50, 0.5, 20, 20, 0, 0], 0, 0, (0.1, 0.1)))
+    R.append((NW, [50, 50, 0.5, 20, 20, 0, 0], 0, 0, (0.35, 0.3499999)))
+    R.append((NW, [50, 50, 0.5, 20, 20, 0, 0], 0, 0, (0.3499999, 0.35)))
+    # boat sitting on the goal centre, not moving relative to it much
+    R.append((NW, [50, 50, 0.0, 50, 50, 0, 0], 0, 0, (0.2, 0.2)))
+    out = []
+    for ci, st, t, ai, ac in R:
+        out.append((ci, f32r(np.array(st, dtype=np.float64)), int(t), int(ai), tuple(f32r(ac))))
+    return out
+
+
+def run_rows(mod, rows):
+    envs = {}
+    cols = {k: [] for k in ("cfg", "state_in", "time_in", "action_i", "action_c", "noise_u", "pose", "reward",
+                            "term", "wave_out", "thrust_total", "m_border", "m_obst", "m_goal", "time_out",
+                            "reward_is_int")}
+    for i, (ci, st, t, ai, ac) in enumerate(rows):
+        if ci not in envs:
+            envs[ci] = make_env(mod, CONFIGS[ci])
+            envs[ci].reset()
+        env = envs[ci]
+        r = record_step(env, CONFIGS[ci][2], st, t, ai, ac, seed=1000 + i)
+        assert np.array_equal(r["goal_out"], st[3:5])
+        cols["cfg"].append(ci)
+        cols["state_in"].append(st)
+        cols["time_in"].append(t)
+        cols["action_i"].append(ai)
+        cols["action_c"].append(ac)
+        for k in ("noise_u", "pose", "reward", "term", "wave_out", "thrust_total", "m_border", "m_obst",
+                  "m_goal", "time_out", "reward_is_int"):
+            cols[k].append(r[k])
+    out = {}
+    for k, v in cols.items():
+        a = np.asarray(v)
+        if k in ("cfg", "time_in", "action_i", "term", "time_out"):
+            a = a.astype(np.int32)
+        elif k == "reward_is_int":
+            a = a.astype(np.uint8)
+        else:
+            a = a.astype(np.float64)
+        out[k] = a
+    return out
+
+
+def gen_trajectories(mod, rng):
+    """free-running reference rollouts (float64 state, seeded global RNG), for the float64 oracle."""
+    out = {}
+    for ti, ci in enumerate((0, 1, 3, 4, 7)):
+        cfg = CONFIGS[ci]
+        continuous = cfg[2]
+        env = make_env(mod, cfg)
+        env.reset()
+        sigma = env.wave_speed_variance
+        T = 260
+        st0 = np.concatenate([env._boat_state, env._goal_state, env._wave_speed])
+        seed = 777 + ti
+        np.random.seed(seed)
+        replay = np.random.RandomState(seed)
+        states, acts_i, acts_c, noise, rew, term = [], [], [], [], [], []
+        for t in range(T):
+            ai = int(rng.randint(3))
+            ac = f32r(rng.uniform(0.2, 0.5, 2))
+            d = replay.uniform(-sigma, sigma, 2)
+            obs, r, done, info = env.step(np.array(ac, dtype=np.float32) if continuous else ai)
+            code = 1 if info["Termination.collided"] else 2 if info["Termination.time"] else \
+                3 if info["Termination.success"] else 0
+            states.append(np.concatenate([obs, env._wave_speed]))
+            acts_i.append(ai)
+            acts_c.append(ac)
+            noise.append(d / sigma)
+            rew.append(float(r))
+            term.append(code)
+        out["traj%d_cfg" % ti] = np.int32(ci)
+        out["traj%d_state0" % ti] = st0
+        out["traj%d_states" % ti] = np.asarray(states)
+        out["traj%d_action_i" % ti] = np.asarray(acts_i, dtype=np.int32)
+        out["traj%d_action_c" % ti] = np.asarray(acts_c)
+        out["traj%d_noise_u" % ti] = np.asarray(noise)
+        out["traj%d_reward" % ti] = np.asarray(rew)
+        out["traj%d_term" % ti] = np.asarray(term, dtype=np.int32)
+    out["n_traj"] = np.int32(5)
+    return out
+
+
+def gen_resets(mod):
+    """samples of the reference's reset() (aqua.py:100-126): distributional target only."""
+    out = {}
+    for ci in (0, 1, 3):
+        env = make_env(mod, CONFIGS[ci])
+        n = 6000
+        S = np.empty((n, 7), dtype=np.float32)
+        for i in range(n):
+            obs = env.reset()
+            assert env.time == 0
+            S[i, 0:5] = obs
+            S[i, 5:7] = env._wave_speed
+        out["reset_cfg%d" % ci] = S
+    # fixed start/goal (aqua.py:107,117)
+    env = mod.AquaEnv(obstacles=True, random_boat=False, random_goal=False)
+    out["reset_fixed"] = env.reset().astype(np.float64)
+    return out
+
+
+def time_reference(mod):
+    print("reference step() timing in this container (1 core, random actions, reset on done)")
+    for ci in (0, 3, 4):
+        cfg = CONFIGS[ci]
+        env = make_env(mod, cfg)
+        env.reset()
+        n, eps, ep_len = 30000, 0, 0
+        acts = [env.action_space.sample() for _ in range(n)]
+        t0 = time.perf_counter()
+        for a in acts:
+            _, _, done, _ = env.step(a)
+            if done:
+                env.reset()
+                eps += 1
+        dt = time.perf_counter() - t0
+        print("  %-22s %9.0f steps/s  %6.1f us/step  mean episode %.0f" %
+              (cfg[0], n / dt, dt / n * 1e6, n / max(eps, 1)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--time", action="store_true", help="also time the reference's step() on this host")
+    args = ap.parse_args()
+    if not os.path.exists(REF):
+        sys.exit("needs %s (build container only)" % REF)
+    mod = load_reference()
+    rng = np.random.RandomState(20261003)
+    rows, tables = gen_rows(mod, rng)
+    rows += hand_rows()
+    n_hand = len(hand_rows())
+    cols = run_rows(mod, rows)
+    cols["n_hand"] = np.int32(n_hand)
+    cols["n_cfg"] = np.int32(len(CONFIGS))
+    for ci, cfg in enumerate(CONFIGS):
+        cols["cfg%d_obstacles" % ci] = tables[ci]
+        cols["cfg%d_continuous" % ci] = np.uint8(cfg[2])
+        cols["cfg%d_waves" % ci] = np.uint8(cfg[3])
+        cols["cfg%d_name" % ci] = np.array(cfg[0])
+    np.savez_compressed(os.path.join(HERE, "step_golden.npz"), **cols)
+    np.savez_compressed(os.path.join(HERE, "traj_golden.npz"), **gen_trajectories(mod, rng))
+    np.savez_compressed(os.path.join(HERE, "reset_golden.npz"), **gen_resets(mod))
+    terms = np.bincount(cols["term"], minlength=4)
+    print("rows", len(rows), "hand", n_hand, "term histogram", terms.tolist())
+    band = (np.abs(cols["m_border"]) < 1e-4) | (np.abs(cols["m_obst"]) < 1e-4) | (np.abs(cols["m_goal"]) < 1e-4)
+    print("rows with a margin inside 1e-4:", int(band.sum()))
+    if args.time:
+        time_reference(mod)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors produced from the reference itself
+(tests/golden/make_golden.py ran the reference's gym_aqua/envs/aqua.py:135-213 unmodified).
+
+CPU only.  Tolerances: float64 vs float64, same operation order -> 1e-9 on pose/reward/wave,
+widened by 8e-16 * |turn radius| (the reference rotates about a centre up to 1.25e8 away,
+aqua.py:159-181, which amplifies 1-ulp sin/cos differences between libm and numpy; at most 1e-7,
+SURVEY.md A.2).
+Termination codes must be equal on EVERY row, including the ~2000 rows whose margin to a
+threshold is below 1e-4.
+"""
+import numpy as np
+import pytest
+
+from tests._golden import StepGolden, load_traj, angle_diff
+from oracle.aqua_oracle import ScalarPort
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return StepGolden()
+
+
+def _soa(rows):
+    state = np.ascontiguousarray(rows["state_in"].T.astype(np.float64))
+    time = np.ascontiguousarray(rows["time_in"].astype(np.int32))
+    return state, time
+
+
+def _action(cfg, rows):
+    if cfg["continuous"]:
+        return np.ascontiguousarray(rows["action_c"].T.astype(np.float32))
+    return rows["action_i"].astype(np.int64)
+
+
+def _tol(cfg, rows):
+    """1e-9, plus the reference's own cancellation noise: it rotates about a centre |r| away
+    (aqua.py:166-181), so a 1-ulp difference in sin/cos between libm and numpy moves the result by
+    ~1e-16 * |r|; |r| reaches 1.25e8 on straight moves."""
+    if cfg["continuous"]:
+        a = np.clip(rows["action_c"], 0.2, 0.5)
+        vl, vr = a[:, 0], a[:, 1]
+    else:
+        tab = np.array([(0.2, 0.5), (0.5, 0.2), (0.5, 0.5)])
+        vl, vr = tab[rows["action_i"], 0], tab[rows["action_i"], 1]
+    d = np.maximum(np.abs(vr - vl), 1e-8)
+    r = 1.25 * (vl + vr) / d
+    return 1e-9 + 8e-16 * r
+
+
+def test_philox_known_answers(oracle):
+    # Random123 v1.09 kat_vectors, philox4x32-10
+    assert oracle.philox((0, 0), (0, 0, 0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xffffffff
+    assert oracle.philox((f, f), (f, f, f, f)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_step_noise_is_24bit_and_shard_invariant(oracle):
+    u, raw = oracle.step_noise(seed=99, env=12345678901, tick=(1 << 40) + 5)
+    assert np.all(u >= -1) and np.all(u < 1)
+    assert np.all(u * 2 ** 23 == np.round(u * 2 ** 23))
+    assert np.float32(u[0]) == u[0]
+    u2, _ = oracle.step_noise(seed=99, env=12345678901, tick=(1 << 40) + 5)
+    assert np.array_equal(u, u2)
+    u3, _ = oracle.step_noise(seed=99, env=12345678902, tick=(1 << 40) + 5)
+    assert not np.array_equal(u, u3)
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_c_oracle_matches_reference_rows(oracle, golden, ci):
+    cfg = golden.cfg(ci)
+    rows = golden.rows(ci)
+    state, time = _soa(rows)
+    noise = np.ascontiguousarray(rows["noise_u"].T)
+    reward, term, margins = oracle.step(state, time, _action(cfg, rows), obstacles=cfg["obstacles"],
+                                        waves=cfg["waves"], noise_u=noise)
+    assert np.array_equal(term, rows["term"].astype(np.uint8)), "termination codes differ from the reference"
+    assert np.array_equal(time, rows["time_out"])
+    tol = _tol(cfg, rows)
+    assert np.all(np.abs(state[0] - rows["pose"][:, 0]) <= tol)
+    assert np.all(np.abs(state[1] - rows["pose"][:, 1]) <= tol)
+    assert np.all(angle_diff(state[2], rows["pose"][:, 2]) <= 1e-12)
+    assert np.all(np.abs(reward - rows["reward"]) <= tol)
+    assert np.all(np.abs(state[5] - rows["wave_out"][:, 0]) <= 1e-15)
+    assert np.all(np.abs(state[6] - rows["wave_out"][:, 1]) <= 1e-15)
+    assert np.array_equal(state[3], rows["state_in"][:, 3]) and np.array_equal(state[4], rows["state_in"][:, 4])
+    # margins as the reference's own helpers report them (aqua.py:404-418, 401-402)
+    assert np.all(np.abs(margins[0] - rows["m_border"]) <= tol)
+    fin = np.isfinite(rows["m_obst"])
+    assert np.all(np.abs(margins[1][fin] - rows["m_obst"][fin]) <= tol[fin])
+    assert np.all(np.isinf(margins[1][~fin]))
+    assert np.all(np.abs(margins[2] - rows["m_goal"]) <= tol)
+
+
+def test_knife_edge_rows_are_present(golden):
+    z = golden.z
+    band = (np.abs(z["m_border"]) < 1e-4) | (np.abs(z["m_obst"]) < 1e-4) | (np.abs(z["m_goal"]) < 1e-4)
+    assert band.sum() > 1500
+    exact = (z["m_border"] == 0) | (z["m_obst"] == 0) | (z["m_goal"] == 0)
+    assert exact.sum() >= 3          # the hand-built "<= vs <" rows
+
+
+def test_hand_rows_known_answers(golden):
+    """values the reference returns for the hand-built cases."""
+    z = golden.z
+    h0 = golden.n - golden.n_hand
+    pose, rew, term = z["pose"][h0:], z["reward"][h0:], z["term"][h0:]
+    # row 0: straight from (50,50,0), goal (50,90), waves off
+    assert pose[0, 0] == 50.0 and abs(pose[0, 1] - 50.5) < 1e-12 and abs(pose[0, 2] - 4e-9) < 1e-15
+    assert abs(rew[0] - 0.35) < 1e-9 and term[0] == 0
+    # rows 1-4: x = 2.5 free, just below collides, 97.5 free, just above collides
+    assert term[1:5].tolist() == [0, 1, 0, 1]
+    # rows 5-8: the same along y (y' = y + 0.5)
+    assert term[5:9].tolist() == [0, 1, 0, 1]
+    # rows 9,10: circle tangent -> collided (<=); 1e-5 further -> free
+    assert term[9] == 1 and term[10] == 0
+    assert z["m_obst"][h0 + 9] == 0.0
+    # rows 11-13: rectangle centre inside (-2.5), edge touch (0.0), corner gap
+    assert z["m_obst"][h0 + 11] == -2.5 and term[11] == 1
+    assert abs(z["m_obst"][h0 + 12]) < 1e-12 and term[12] == 1
+    assert abs(z["m_obst"][h0 + 13] - 1.7426406871192848) < 1e-9 and term[13] == 0
+    # row 14: collision + goal -> collision; rows 15,16: time beats goal at 1001, goal wins at 1000
+    assert term[14] == 1 and rew[14] == -10
+    assert term[15] == 2 and rew[15] == -10
+    assert term[16] == 3 and rew[16] == 10
+    assert term[17] == 2 and term[18] == 2
+    # rows 19-22: angle wrap stays in [-pi, pi)
+    # (theta_in was rounded to float32 before the step: f32(pi - 0.05) + 0.12 - 2 pi)
+    assert abs(pose[19, 2] - (float(np.float32(np.pi - 0.05)) + 0.12 - 2 * np.pi)) < 1e-12
+    assert np.all(pose[19:23, 2] >= -np.pi) and np.all(pose[19:23, 2] < np.pi)
+    # terminal rewards are Python ints in the reference, step rewards floats
+    assert np.all(z["reward_is_int"][h0:][term != 0] == 1) and np.all(z["reward_is_int"][h0:][term == 0] == 0)
+
+
+@pytest.mark.parametrize("ci", [0, 3, 4, 6])
+def test_scalar_port_matches_reference_rows(golden, ci):
+    """the one-env-per-object numpy port (bench.py's CPU baseline) on a subset of rows."""
+    cfg = golden.cfg(ci)
+    rows = golden.rows(ci)
+    env = ScalarPort(obstacles=cfg["obstacles"], waves=cfg["waves"], continuous=cfg["continuous"])
+    tols = _tol(cfg, rows)
+    for i in range(0, rows["term"].shape[0], 3):
+        s = rows["state_in"][i]
+        env.set_state(s[0:3], s[3:5], s[5:7], rows["time_in"][i])
+        a = rows["action_c"][i].astype(np.float32) if cfg["continuous"] else int(rows["action_i"][i])
+        obs, rew, done, info = env.step(a, noise_u=rows["noise_u"][i])
+        code = 1 if info["Termination.collided"] else 2 if info["Termination.time"] else \
+            3 if info["Termination.success"] else 0
+        assert code == rows["term"][i] and done == (code != 0)
+        tol = tols[i]
+        assert np.all(np.abs(obs[0:2] - rows["pose"][i, 0:2]) <= tol)
+        assert angle_diff(obs[2], rows["pose"][i, 2]) <= 1e-12
+        assert abs(rew - rows["reward"][i]) <= tol
+        assert np.all(np.abs(env.wave - rows["wave_out"][i]) <= 1e-15)
+        assert isinstance(rew, int) == bool(rows["reward_is_int"][i])
+
+
+def test_c_oracle_reproduces_reference_trajectories(oracle):
+    """free-running float64 rollouts of the reference (seeded global RNG) replayed with injected noise."""
+    z = load_traj()
+    g = StepGolden()
+    for ti in range(int(z["n_traj"])):
+        cfg = g.cfg(int(z["traj%d_cfg" % ti]))
+        state = np.ascontiguousarray(z["traj%d_state0" % ti].reshape(7, 1).astype(np.float64))
+        time = np.zeros(1, dtype=np.int32)
+        want = z["traj%d_states" % ti]
+        for t in range(want.shape[0]):
+            if cfg["continuous"]:
+                a = np.ascontiguousarray(z["traj%d_action_c" % ti][t].reshape(2, 1).astype(np.float32))
+            else:
+                a = z["traj%d_action_i" % ti][t:t + 1].astype(np.int64)
+            rew, term, _ = oracle.step(state, time, a, obstacles=cfg["obstacles"], waves=cfg["waves"],
+                                       noise_u=z["traj%d_noise_u" % ti][t].reshape(2, 1))
+            assert term[0] == z["traj%d_term" % ti][t]
+            assert abs(rew[0] - z["traj%d_reward" % ti][t]) < 1e-6
+            assert np.all(np.abs(state[[0, 1, 5, 6], 0] - want[t][[0, 1, 5, 6]]) < 1e-6)
+            assert angle_diff(state[2, 0], want[t][2]) < 1e-9
+            # the reference does not freeze or reset after done (aqua.py has no guard): keep stepping
+        assert time[0] == want.shape[0]
+
+
+def test_discrete_action_index_wraps_like_a_python_list(oracle):
+    s0 = np.array([[40.0], [60.0], [1.0], [70.0], [20.0], [0.0], [0.0]])
+    outs = []
+    for a in (-1, 2, -3, 0):
+        s = s0.copy()
+        t = np.zeros(1, dtype=np.int32)
+        oracle.step(s, t, np.array([a], dtype=np.int64), waves=0, noise_u=np.zeros((2, 1)))
+        outs.append(s[:, 0].copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[3])
