@@ -1,0 +1,341 @@
+"""BatchedAqua: N independent AquaEnv worlds advanced in lock-step on one MI355X.
+
+Host-side owner of the device buffers (PyTorch tensors used as raw HBM allocations) and caller of
+the C ABI in include/aqua_hip.h.  There is no CPU path: constructing it without a HIP device or
+without libaqua_hip.so raises.
+
+Reference being replaced: one Python object per world, gym_aqua/envs/aqua.py:9-213.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _capi, presets
+
+TIME_LIMIT = 1000          # aqua.py:91
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class RolloutGraph(object):
+    """A captured HIP graph of T batched steps (+ the device tick bump); replay with launch()."""
+
+    def __init__(self, env, handle, steps, reward, term):
+        self._env = env
+        self._handle = handle
+        self.steps = steps
+        self.reward = reward
+        self.term = term
+
+    def launch(self):
+        env = self._env
+        env._sync_device_tick()
+        _capi.check(_capi.lib.aqua_graph_launch(self._handle, env._stream()), "aqua_graph_launch")
+        env._tick += self.steps
+        env._device_tick += self.steps
+        return self.reward, self.term
+
+    def close(self):
+        if self._handle is not None:
+            _capi.lib.aqua_graph_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchedAqua(object):
+    """N worlds in struct-of-arrays float32 buffers on one GPU.
+
+    state   float32 [7][ld]   x, y, theta, goal_x, goal_y, wave_x, wave_y   (rows 0..4 are the observation)
+    time    int32   [ld]
+    reward  float32 [ld],  term uint8 [ld] (0 none, 1 collided, 2 time, 3 success)
+    done_bits int64 [ceil(N/64)] (bit-packed done mask straight from the wavefront ballots)
+    """
+
+    def __init__(self, num_envs, obstacles=False, waves=True, random_boat=True, random_goal=True, continuous=False,
+                 device=None, seed=None, env_offset=0, auto_reset=True):
+        import torch
+        self.torch = torch
+        if num_envs < 1:
+            raise ValueError("num_envs must be >= 1")
+        dev = torch.device("cuda" if device is None else device)
+        if dev.type != "cuda":
+            raise RuntimeError("BatchedAqua runs on an AMD GPU through HIP only (device=%r); there is no CPU path" % (device,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: BatchedAqua has no CPU path")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.num_envs = int(num_envs)
+        self.env_offset = int(env_offset)
+        self.continuous = bool(continuous)
+        self.auto_reset = bool(auto_reset)
+        self.has_waves = int(waves)                   # aqua.py:15
+        self.seed = int(seed) if seed is not None else int(np.random.SeedSequence().entropy & ((1 << 64) - 1))
+        self.obstacle_rows = presets.rows_from(obstacles)
+        self.K = int(self.obstacle_rows.shape[0])
+        self.params = _capi.AquaParams(waves=self.has_waves, continuous=int(self.continuous),
+                                       random_boat=int(bool(random_boat)), random_goal=int(bool(random_goal)),
+                                       time_limit=TIME_LIMIT)
+        n = self.num_envs
+        self.ld = _round_up(n, 64)
+        with torch.cuda.device(dev):
+            self.state = torch.zeros((7, self.ld), dtype=torch.float32, device=dev)
+            self.time = torch.zeros(self.ld, dtype=torch.int32, device=dev)
+            self.reward = torch.zeros(self.ld, dtype=torch.float32, device=dev)
+            self.term = torch.zeros(self.ld, dtype=torch.uint8, device=dev)
+            self.done_bits = torch.zeros(self.ld // 64, dtype=torch.int64, device=dev)
+            blob = _capi.pack_obstacles(self.obstacle_rows)
+            if blob:
+                host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+                self._blob = host.to(dev)
+            else:
+                self._blob = None
+            self._tick_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._tick = 0
+        self._device_tick = 0
+        self._action_soa = None           # staging for (N, 2) -> [2][ld] continuous actions
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _blob_ptr(self):
+        return self._blob.data_ptr() if self._blob is not None else None
+
+    def _sync_device_tick(self):
+        if self._device_tick != self._tick:
+            self._tick_dev.fill_(self._tick)
+            self._device_tick = self._tick
+
+    @property
+    def obs(self):
+        """[N, 5] view (x, y, theta, goal_x, goal_y) of the state rows -- no copy (aqua.py:213)."""
+        return self.state[:5, :self.num_envs].t()
+
+    @property
+    def wave(self):
+        return self.state[5:7, :self.num_envs].t()
+
+    def _as_action(self, action, soa=False):
+        """-> (tensor kept alive, pointer, kind, action_ld)"""
+        torch = self.torch
+        n = self.num_envs
+        if self.continuous:
+            a = action
+            if not isinstance(a, torch.Tensor):
+                a = torch.as_tensor(np.asarray(a, dtype=np.float32))
+            a = a.to(device=self.device, dtype=torch.float32)
+            if soa:
+                if a.dim() != 2 or a.shape[0] != 2 or a.shape[1] < n or a.stride(1) != 1:
+                    raise ValueError("soa action must be a float32 [2][>=N] tensor with unit inner stride")
+                return a, a.data_ptr(), _capi.ACT_F32X2, a.stride(0)
+            if a.dim() == 1 and n == 1:
+                a = a.reshape(1, 2)
+            if a.shape != (n, 2):
+                raise ValueError("continuous action must have shape (%d, 2), got %s" % (n, tuple(a.shape)))
+            if self._action_soa is None:
+                self._action_soa = torch.empty((2, self.ld), dtype=torch.float32, device=self.device)
+            self._action_soa[:, :n].copy_(a.t())
+            return self._action_soa, self._action_soa.data_ptr(), _capi.ACT_F32X2, self.ld
+        a = action
+        if not isinstance(a, torch.Tensor):
+            arr = np.asarray(a)
+            if arr.dtype.kind not in "iu":
+                raise TypeError("discrete actions must be integers, got dtype %s" % arr.dtype)
+            a = torch.as_tensor(arr.astype(np.int64).reshape(-1))
+        if a.dtype == torch.uint8:
+            kind = _capi.ACT_U8
+        elif a.dtype == torch.int32:
+            kind = _capi.ACT_I32
+        elif a.dtype == torch.int64:
+            kind = _capi.ACT_I64
+        else:
+            raise TypeError("discrete actions must be uint8 / int32 / int64, got %s" % a.dtype)
+        a = a.to(self.device).reshape(-1)
+        if a.numel() != n or not a.is_contiguous():
+            if a.numel() != n:
+                raise ValueError("expected %d actions, got %d" % (n, a.numel()))
+            a = a.contiguous()
+        return a, a.data_ptr(), kind, 0
+
+    # ------------------------------------------------------------------ the path
+    def reset(self, mask=None):
+        """(Re)start worlds: all of them, or those with mask[i] != 0 (uint8/bool tensor).  aqua.py:100-126."""
+        torch = self.torch
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device)
+            if mask.dtype == torch.bool:
+                mask = mask.to(torch.uint8)
+            if mask.dtype != torch.uint8 or mask.numel() < self.num_envs:
+                raise ValueError("mask must be a uint8/bool tensor with one entry per world")
+            mask = mask.contiguous()
+            mptr = mask.data_ptr()
+        with torch.cuda.device(self.device):
+            _capi.check(_capi.lib.aqua_reset_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                                 self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
+                                                 mptr, self.seed, self._tick, None, self._stream()), "aqua_reset_f32")
+        self._tick += 1
+        return self.obs
+
+    def step(self, action=None, soa=False, noise=None, sample_actions=False):
+        """One batched step (aqua.py:135-213).  Returns (obs view [N,5], reward [N], term [N] uint8).
+        noise: optional float32 [2][>=N] uniforms in [-1, 1) replacing the Philox draws (parity tests)."""
+        torch = self.torch
+        n = self.num_envs
+        if sample_actions:
+            keep, aptr, kind, ald = None, None, (_capi.ACT_SAMPLE_C if self.continuous else _capi.ACT_SAMPLE_D), 0
+        else:
+            keep, aptr, kind, ald = self._as_action(action, soa)
+        nptr, nld = None, 0
+        if noise is not None:
+            if noise.dtype != torch.float32 or noise.dim() != 2 or noise.shape[0] != 2 or noise.shape[1] < n \
+                    or noise.stride(1) != 1:
+                raise ValueError("noise must be float32 [2][>=N] with unit inner stride")
+            nptr, nld = noise.data_ptr(), noise.stride(0)
+        with torch.cuda.device(self.device):
+            _capi.check(_capi.lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
+                                                self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald,
+                                                nptr, nld, self.seed, self._tick, None, self.reward.data_ptr(),
+                                                self.term.data_ptr(), self.done_bits.data_ptr(), int(self.auto_reset),
+                                                self._stream()), "aqua_step_f32")
+        self._tick += 1
+        del keep
+        return self.obs, self.reward[:n], self.term[:n]
+
+    def _rollout_args(self, steps, actions, soa_ld):
+        torch = self.torch
+        n = self.num_envs
+        if actions is None:
+            return None, (_capi.ACT_SAMPLE_C if self.continuous else _capi.ACT_SAMPLE_D), 0, 0
+        if self.continuous:
+            if actions.dtype != torch.float32 or actions.dim() != 3 or actions.shape[0] < steps or actions.shape[1] != 2 \
+                    or actions.shape[2] < n or actions.stride(2) != 1:
+                raise ValueError("continuous rollout actions must be float32 [T][2][>=N]")
+            return actions.data_ptr(), _capi.ACT_F32X2, actions.stride(1), actions.stride(0)
+        kinds = {torch.uint8: _capi.ACT_U8, torch.int32: _capi.ACT_I32, torch.int64: _capi.ACT_I64}
+        if actions.dtype not in kinds or actions.dim() != 2 or actions.shape[0] < steps or actions.shape[1] < n \
+                or actions.stride(1) != 1:
+            raise ValueError("discrete rollout actions must be uint8/int32/int64 [T][>=N]")
+        return actions.data_ptr(), kinds[actions.dtype], 0, actions.stride(0)
+
+    def _rollout_out(self, steps, keep_all):
+        torch = self.torch
+        if keep_all:
+            reward = torch.empty((steps, self.ld), dtype=torch.float32, device=self.device)
+            term = torch.empty((steps, self.ld), dtype=torch.uint8, device=self.device)
+            return reward, term, self.ld
+        return self.reward, self.term, 0
+
+    def _done_out(self, steps, done_history):
+        """done_history: None -> every step overwrites self.done_bits; True -> a fresh int64 [T][ld/64]
+        tensor; or a caller-provided tensor of that shape (e.g. one half of a double buffer)."""
+        torch = self.torch
+        if done_history is None or done_history is False:
+            return self.done_bits, 0
+        if done_history is True:
+            done_history = torch.zeros((steps, self.ld // 64), dtype=torch.int64, device=self.device)
+        if done_history.dtype != torch.int64 or done_history.dim() != 2 or done_history.shape[0] < steps \
+                or done_history.shape[1] < self.ld // 64 or done_history.stride(1) != 1:
+            raise ValueError("done_history must be int64 [T][>= ld/64]")
+        return done_history, done_history.stride(0)
+
+    def rollout(self, steps, actions=None, fused=False, keep_all=True, done_history=None):
+        """`steps` consecutive batched steps queued from C without returning to Python.
+        actions: None -> uniform random actions sampled on the device from the step's Philox draw;
+                 discrete: uint8/int32/int64 [T][>=N]; continuous: float32 [T][2][>=N].
+        fused=True runs them as ONE launch with the state held in registers.
+        Returns (reward, term): [T][ld] tensors when keep_all, else the last step's [ld] buffers."""
+        torch = self.torch
+        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld)
+        reward, term, ostride = self._rollout_out(steps, keep_all)
+        done, dstride = self._done_out(steps, done_history)
+        lib = _capi.lib
+        with torch.cuda.device(self.device):
+            if fused:
+                _capi.check(lib.aqua_rollout_fused_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                                       self.env_offset, self.state.data_ptr(), self.ld,
+                                                       self.time.data_ptr(), steps, aptr, kind, ald, astride, self.seed,
+                                                       self._tick, None, reward.data_ptr(), term.data_ptr(), ostride,
+                                                       int(self.auto_reset), self._stream()), "aqua_rollout_fused_f32")
+            else:
+                _capi.check(lib.aqua_rollout_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                                 self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
+                                                 steps, aptr, kind, ald, astride, self.seed, self._tick, None,
+                                                 reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(),
+                                                 dstride, int(self.auto_reset), self._stream()), "aqua_rollout_f32")
+        self._tick += steps
+        return reward, term
+
+    def capture_rollout(self, steps, actions=None, fused=False, keep_all=False, done_history=None):
+        """Capture `steps` batched steps into a HIP graph.  Noise stays fresh across replays: the
+        kernels add a device-resident tick base that the graph's last node advances by `steps`."""
+        torch = self.torch
+        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld)
+        reward, term, ostride = self._rollout_out(steps, keep_all)
+        done, dstride = self._done_out(steps, done_history)
+        lib = _capi.lib
+        self._sync_device_tick()
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device), torch.cuda.stream(cap):
+            s = self._stream()
+            _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
+            try:
+                tb = self._tick_dev.data_ptr()
+                if fused:
+                    rc = lib.aqua_rollout_fused_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                                    self.env_offset, self.state.data_ptr(), self.ld,
+                                                    self.time.data_ptr(), steps, aptr, kind, ald, astride, self.seed, 0,
+                                                    tb, reward.data_ptr(), term.data_ptr(), ostride,
+                                                    int(self.auto_reset), s)
+                else:
+                    rc = lib.aqua_rollout_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                              self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
+                                              steps, aptr, kind, ald, astride, self.seed, 0, tb, reward.data_ptr(),
+                                              term.data_ptr(), ostride, done.data_ptr(), dstride,
+                                              int(self.auto_reset), s)
+                if rc == 0:
+                    rc = lib.aqua_tick_advance(tb, steps, s)
+            finally:
+                rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
+            _capi.check(rc, "capture rollout")
+            _capi.check(rc_end, "aqua_graph_end")
+        torch.cuda.current_stream(self.device).wait_stream(cap)
+        g = RolloutGraph(self, handle, steps, reward, term)
+        g._actions = actions          # keep the action buffer alive as long as the graph
+        g.done_history = done if dstride else None
+        return g
+
+    # ------------------------------------------------------------------ helpers
+    def done_mask(self):
+        """uint8 [N] done flags unpacked from the ballot words (for checks; step() already returns term)."""
+        torch = self.torch
+        words = self.done_bits[: (self.num_envs + 63) // 64]
+        shifts = torch.arange(64, device=self.device, dtype=torch.int64)
+        bits = (words.unsqueeze(1) >> shifts) & 1
+        return bits.reshape(-1)[: self.num_envs].to(torch.uint8)
+
+    def set_state(self, state7, time=None, soa=False):
+        """Overwrite the worlds' state (teacher forcing in tests): float [N][7], or [7][N] with soa=True."""
+        torch = self.torch
+        s = torch.as_tensor(np.asarray(state7, dtype=np.float32)) if not isinstance(state7, torch.Tensor) else state7
+        s = s.to(device=self.device, dtype=torch.float32)
+        if not soa:
+            if s.shape != (self.num_envs, 7):
+                raise ValueError("state must be [N][7]")
+            s = s.t()
+        if s.shape != (7, self.num_envs):
+            raise ValueError("state must be [7][N]")
+        self.state[:, : self.num_envs].copy_(s)
+        if time is not None:
+            t = torch.as_tensor(np.asarray(time, dtype=np.int32)) if not isinstance(time, torch.Tensor) else time
+            self.time[: self.num_envs].copy_(t.to(device=self.device, dtype=torch.int32))

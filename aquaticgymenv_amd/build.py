@@ -1,0 +1,48 @@
+"""Build libaqua_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+The shared object lands in aquaticgymenv_amd/lib/ so that it travels with the source tree to the
+GPU box (a JIT cache under $HOME would not).  hipcc cross-compiles for gfx950 without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", "aqua_hip.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "aqua_device.hpp"),
+              os.path.join(os.path.dirname(HERE), "include", "aqua_hip.h")]
+LIB = os.path.join(HERE, "lib", "libaqua_hip.so")
+ARCH = "gfx950"
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    """Compile csrc/aqua_hip.hip -> lib/libaqua_hip.so for gfx950.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc_path(), "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-shared", "-fPIC",
+           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB + ".tmp", *SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,162 @@
+/*
+ * aqua_hip.h -- C ABI of libaqua_hip.so: the batched AquaEnv step()/reset() hot path on MI355X (gfx950).
+ *
+ * The reference (ilVecc/AquaticGymEnv) is pure Python and has no native layer, so there is no
+ * existing FFI to mirror; every entry point below names the reference interface it replaces
+ * (file:line under the reference root).  The host-side binding is ctypes
+ * (aquaticgymenv_amd/_capi.py); INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / HIP types in signatures (streams are void*).
+ *  - every DEVICE buffer is owned by the caller; the library borrows the pointers for the duration
+ *    of the call (asynchronously: until the work queued on `stream` has run), allocates nothing,
+ *    frees nothing and keeps no pointer afterwards.  The only objects the library owns are the
+ *    AquaGraph handles returned by aqua_graph_end().
+ *  - launches are asynchronous on `stream`; no entry point synchronises the device, so all of
+ *    them may be captured into a HIP graph.
+ *  - return value: 0 = ok; > 0 = hipError_t; < 0 = AQUA_E_*.  aqua_last_error() returns a
+ *    thread-local message for the last failing call on this thread.
+ *  - thread safety: no global mutable state; calls on different streams may come from
+ *    different host threads.
+ *
+ * State layout (struct of arrays, float32): `state` points at 7 rows of `ld` floats:
+ *      row 0 x, 1 y, 2 theta, 3 goal_x, 4 goal_y, 5 wave_x, 6 wave_y        (ld >= N)
+ * Rows 0..4 ARE the observation of aqua.py:213 (obs[:, k] = state[k*ld + i]); nothing is copied.
+ * `time` is int32[N] (aqua.py:82,141).  Vectorised (16-byte) access is used when `state`,
+ * `time`, `reward` are 16-byte aligned and ld % 4 == 0; otherwise a scalar kernel runs.
+ */
+#ifndef AQUA_HIP_H
+#define AQUA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQUA_ABI_VERSION 1
+
+/* library error codes (negative) */
+#define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
+#define AQUA_E_ALIGN     (-2)   /* pointer / leading dimension not usable */
+#define AQUA_E_NODEVICE  (-3)   /* no HIP device / wrong architecture */
+
+/* action encodings accepted by aqua_step_f32 (aqua.py:33-43,137-154) */
+#define AQUA_ACT_U8        0    /* uint8[N]   discrete index 0..2 */
+#define AQUA_ACT_I32       1    /* int32[N]   discrete; -3..-1 wrap like a Python list index */
+#define AQUA_ACT_I64       2    /* int64[N]   discrete */
+#define AQUA_ACT_F32X2     3    /* float32 [2][action_ld]: row 0 vL, row 1 vR (continuous, clipped to [0.2, 0.5]) */
+#define AQUA_ACT_SAMPLE_D  4    /* no buffer: uniform discrete action from the step's Philox draw (word 2) */
+#define AQUA_ACT_SAMPLE_C  5    /* no buffer: vL, vR ~ U[0.2, 0.5) from the step's Philox draw (words 2, 3) */
+
+/* termination codes written to `term` (aqua.py:194-211, exactly one info flag is True when done) */
+#define AQUA_TERM_NONE     0
+#define AQUA_TERM_COLLIDED 1    /* 'Termination.collided' */
+#define AQUA_TERM_TIME     2    /* 'Termination.time'     */
+#define AQUA_TERM_SUCCESS  3    /* 'Termination.success'  */
+
+#define AQUA_MAX_OBSTACLES 64
+
+/* Constructor arguments of the reference's AquaEnv (aqua.py:13-31) that change the arithmetic. */
+typedef struct AquaParams {
+    int32_t waves;          /* int(waves): scales wave bound 0.05 and wave step 0.001 (aqua.py:15,23-25) */
+    int32_t continuous;     /* AquaContinuousEnv (aqua.py:458-459); only used by reset/sampling paths      */
+    int32_t random_boat;    /* aqua.py:110-117 */
+    int32_t random_goal;    /* aqua.py:102-107 */
+    int32_t time_limit;     /* aqua.py:91 (1000) */
+    int32_t reserved[3];
+} AquaParams;
+
+int aqua_version(void);                 /* AQUA_ABI_VERSION */
+const char* aqua_last_error(void);
+
+/*
+ * Obstacle table.  Replaces the per-object Python list of aqua.py:56-68.
+ * rows: host float64 [K][5] = cx, cy, kind (0 circle | 1 rectangle), a (radius | width), b (0 | height).
+ * aqua_pack_obstacles() writes the device-format blob (float32 clamp boxes + squared thresholds
+ * for the fast path, then the float64 rows for the exact path) into HOST memory; the caller
+ * uploads it and passes the device copy to the calls below.  K == 0 -> blob of 0 bytes, pass NULL.
+ */
+size_t aqua_obstacle_blob_bytes(int K);
+int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_bytes);
+
+/*
+ * One batched step: replaces AquaEnv.step(action) (aqua.py:135-213) for N worlds.
+ *   N, env_offset : this call advances global worlds [env_offset, env_offset + N); the Philox
+ *                   stream is keyed by the GLOBAL index so any range partition gives the same result.
+ *   action        : see AQUA_ACT_*; action_ld is the row stride of AQUA_ACT_F32X2 (ignored otherwise).
+ *   noise         : NULL -> the two wave draws of aqua.py:188 come from Philox4x32-10
+ *                   (key = seed, counter = (global env, tick)); else float32 [2][noise_ld] of
+ *                   uniforms in [-1, 1) that are multiplied by 0.001*waves (injection, for parity tests).
+ *   tick          : step counter of the caller; tick_base_dev (nullable, device uint64) is added to
+ *                   it on the device so a captured graph can be replayed with fresh noise.
+ *   reward        : float32[N]; term: uint8[N] (AQUA_TERM_*); done_bits: uint64[ceil(N/64)] or NULL,
+ *                   bit (i % 64) of word (i / 64) = done flag of local world i (wavefront ballot).
+ *   auto_reset    : != 0 -> worlds that finished are re-initialised in the same launch exactly as
+ *                   aqua_reset_f32(mask = term != 0) would; reward/term/done_bits still describe the
+ *                   step that finished.  == 0 -> the reference's behaviour: no freeze, no reset.
+ */
+int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
+                  float* state, int64_t ld, int32_t* time, const void* action, int action_kind,
+                  int64_t action_ld, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t tick,
+                  const uint64_t* tick_base_dev, float* reward, uint8_t* term, uint64_t* done_bits,
+                  int auto_reset, void* stream);
+
+/*
+ * Masked reset: replaces AquaEnv.reset() (aqua.py:100-126) for the worlds with mask[i] != 0
+ * (mask == NULL: all N).  Rejection sampling in float32 from Philox streams 1..3 (DESIGN.md "RNG").
+ */
+int aqua_reset_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
+                   float* state, int64_t ld, int32_t* time, const uint8_t* mask, uint64_t seed, uint64_t tick,
+                   const uint64_t* tick_base_dev, void* stream);
+
+/*
+ * T consecutive steps, one launch per step (the rollout loop of main/testing/__init__.py:25-34 and
+ * main/impl/dqn.py:159-179 with the policy replaced by a pre-generated or sampled action stream).
+ *   actions       : AQUA_ACT_U8/I32/I64: [T][action_step_stride elements]; AQUA_ACT_F32X2: T blocks of
+ *                   [2][action_ld]; AQUA_ACT_SAMPLE_*: NULL.  action_step_stride is in ELEMENTS.
+ *   reward, term  : per-step outputs, step t writes at + t*out_step_stride elements (0 = overwrite).
+ *   done_bits     : likewise with done_step_stride (in uint64 words; 0 = overwrite; NULL = skip).
+ */
+int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
+                     float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
+                     int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
+                     const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
+                     uint64_t* done_bits, int64_t done_step_stride, int auto_reset, void* stream);
+
+/*
+ * The same T steps fused into ONE launch: pose, goal, wave and time stay in registers between
+ * steps, so HBM traffic per world-step drops to the action read and the reward/term writes.
+ * Results are identical to aqua_rollout_f32 with the same arguments (tests/test_hip_parity.py).
+ */
+int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
+                           float* state, int64_t ld, int32_t* time, int64_t T, const void* actions,
+                           int action_kind, int64_t action_ld, int64_t action_step_stride, uint64_t seed,
+                           uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                           int64_t out_step_stride, int auto_reset, void* stream);
+
+/* *tick_base_dev += delta, as a 1-thread kernel on `stream` (the last node of a captured rollout graph). */
+int aqua_tick_advance(uint64_t* tick_base_dev, uint64_t delta, void* stream);
+
+/* HIP-graph helpers: capture whatever is launched on `stream` between begin and end, replay it. */
+typedef struct AquaGraph AquaGraph;
+int aqua_graph_begin(void* stream);
+int aqua_graph_end(void* stream, AquaGraph** out);
+int aqua_graph_launch(AquaGraph* g, void* stream);
+int aqua_graph_destroy(AquaGraph* g);
+
+/* Introspection for tests and bench: which kernel variant a call with these arguments would run. */
+int aqua_step_vector_width(const float* state, int64_t ld, const int32_t* time, const float* reward,
+                           const void* action, int action_kind, int64_t action_ld, const float* noise,
+                           int64_t noise_ld, const uint8_t* term);
+/* the float32 constants the kernels use for the three discrete actions (aqua.py:33-42 folded through
+ * aqua.py:159-170): out = h[3] (w/2), w[3], chord[3]; for tests. */
+void aqua_discrete_constants(float out[9]);
+/* override the automatic choice (0 = auto, 1, 2 or 4 worlds per lane); returns the previous value. */
+int aqua_set_vector_width(int width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQUA_HIP_H */
