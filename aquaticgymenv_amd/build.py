@@ -14,6 +14,9 @@ DEPS = SRC + [os.path.join(HERE, "csrc", "aqua_device.hpp"),
               os.path.join(os.path.dirname(HERE), "include", "aqua_hip.h")]
 LIB = os.path.join(HERE, "lib", "libaqua_hip.so")
 ARCH = "gfx950"
+# -fno-honor-nans: no state ever holds a NaN; it drops the v_max(x, x) canonicalisation in front of every
+# fmin/fmax (results for non-NaN inputs are unchanged; contraction is controlled per function by pragmas)
+COMMON_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-shared", "-fPIC", "-fno-honor-nans"]
 
 
 def hipcc_path():
@@ -35,8 +38,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc_path(), "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB + ".tmp", *SRC]
+    cmd = [hipcc_path(), *COMMON_FLAGS, "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB + ".tmp", *SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -44,5 +46,22 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+def build_variant(name, flags, verbose=False):
+    """Tuning builds for A/B timing (tools/ablate.py): lib/variants/libaqua_hip_<name>.so with extra -D flags.
+    Select one at run time with AQUA_HIP_LIB=<path>."""
+    out = os.path.join(HERE, "lib", "variants", "libaqua_hip_%s.so" % name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [hipcc_path(), *COMMON_FLAGS, *flags, "-o", out, *SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
+    if "--variants" in sys.argv:
+        for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("tile512", ["-DAQUA_TILE=512"]),
+                            ("tile1024_lds", ["-DAQUA_OBST_LDS=1"]), ("group4", ["-DAQUA_RESET_GROUP=4"]),
+                            ("group16", ["-DAQUA_RESET_GROUP=16"])):
+            print(build_variant(name, flags, verbose=True))
     print(build_hip(force="--force" in sys.argv, verbose=True))

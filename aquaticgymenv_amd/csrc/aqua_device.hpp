@@ -19,14 +19,29 @@ constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band, i
 constexpr int RESET_TRIES = 64;
 constexpr int MAX_OBST = 64;
 
-// one obstacle in fast-path form: clamp box (a circle is a degenerate box) + squared thresholds
+// one obstacle in fast-path form: a box (a circle is a box with zero half extents) inflated by R
 struct ObstF {
-    float lox, loy, hix, hiy;   // nearest-point clamp box (aqua.py:381-388); circle: lo == hi == centre
-    float lo2, hi2;             // (R - BAND)^2, (R + BAND)^2 with R = obstacle radius + 2.5 (circle) or 2.5 (rect)
+    float cx, cy, hx, hy;       // box centre and half extents (aqua.py:381-384); circle: hx = hy = 0
+    float a, b;                 // a = 1 / (2R), b = -R / 2 with R = obstacle radius + 2.5 (circle) or 2.5 (rect):
+                                //   m = a * d^2 + b = (d^2 - R^2) / (2R) has the sign of (d - R) and ~ its size near 0
     float r2;                   // R^2, used by the float32 reset specification
     float pad;
 };
 static_assert(sizeof(ObstF) == 32, "ObstF is two float4");
+
+// Where the per-batch obstacle table is read from.  Default: straight from the packed blob through the
+// CONSTANT address space -- every lane reads the same row, so the loads are scalar (s_load_dwordx4 into
+// SGPRs, served by the scalar cache) and the rows cost no VGPRs, no LDS round trip and no barrier.
+// -DAQUA_OBST_LDS=1 builds the variant that stages the table into LDS once per workgroup instead
+// (kept for A/B measurements and as the base of per-world tables; DESIGN.md "Obstacle table").
+#ifndef AQUA_OBST_LDS
+#define AQUA_OBST_LDS 0
+#endif
+#if AQUA_OBST_LDS
+using ObstPtr = const ObstF*;
+#else
+using ObstPtr = const ObstF __attribute__((address_space(4)))*;
+#endif
 
 struct EnvState {               // registers of one world
     float x, y, th, gx, gy, wx, wy;
@@ -38,7 +53,7 @@ struct StepConst {              // wave-uniform
     int waves;
     int time_limit;             // aqua.py:91
     int K;
-    const ObstF* obst;          // LDS copy of the float32 table
+    ObstPtr obst;               // float32 table (scalar-loaded from the blob, or the LDS copy)
     const double* obst64;       // global float64 rows [K][5] (exact path)
 };
 
@@ -53,8 +68,11 @@ constexpr float ACT_H_LINE = 0x1.12e0bep-29f, ACT_W_LINE = 0x1.12e0bep-28f, ACT_
 // ------------------------------------------------------------------------------------ Philox
 // Philox4x32-10 (Salmon et al., SC'11).  key = seed; counter = (env lo, env hi, tick lo,
 // tick hi[15:0] | attempt << 16 | stream << 24).
-enum : uint32_t { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3 };
+// Streams 0 (step noise) and 4 (sampled actions) are drawn per PAIR of worlds: counter env = world >> 1,
+// the even world uses words 0,1 and the odd world words 2,3 -- a lane that owns two worlds makes one call.
+enum : uint32_t { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3, STREAM_ACT = 4 };
 
+template <bool SCALAR_KEY = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
                                                uint32_t c3, uint32_t (&out)[4])
 {
@@ -67,15 +85,20 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
+        // keep the key schedule a running pair of scalars: without this the ten round keys are
+        // hoisted into twenty long-lived SGPRs and spill into VGPR lanes (v_readlane per round)
+        if constexpr (SCALAR_KEY) asm volatile("" : "+s"(k0), "+s"(k1));
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// SCALAR_KEY: the caller guarantees `seed` is wave-uniform and lives in SGPRs (kernel arguments)
+template <bool SCALAR_KEY = false>
 __device__ __forceinline__ void draw(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, uint32_t attempt,
                                       uint32_t (&out)[4])
 {
     const uint32_t c3 = (static_cast<uint32_t>(tick >> 32) & 0xFFFFu) | ((attempt & 0xFFu) << 16) | (stream << 24);
-    philox4x32_10(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), static_cast<uint32_t>(env),
+    philox4x32_10<SCALAR_KEY>(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), static_cast<uint32_t>(env),
                   static_cast<uint32_t>(env >> 32), static_cast<uint32_t>(tick), c3, out);
 }
 
@@ -120,9 +143,9 @@ __device__ __forceinline__ float wrap_add(float th, float w)
     constexpr float PI_F = 3.14159274101257324f;
     constexpr float TWO_PI_HI = 6.28318548202514648f, TWO_PI_LO = -1.74845553146951715e-07f;
     float s = th + w;
-    if (s >= PI_F) s = (s - TWO_PI_HI) - TWO_PI_LO;
-    else if (s <= -PI_F) s = (s + TWO_PI_HI) + TWO_PI_LO;
-    return s;
+    const float turns = s >= PI_F ? -1.0f : (s <= -PI_F ? 1.0f : 0.0f);
+    s = fmaf(turns, TWO_PI_HI, s);           // exact (Sterbenz range), then the low part of 2 pi
+    return fmaf(turns, TWO_PI_LO, s);
 }
 
 // continuous thrusts -> (h, w, chord) (aqua.py:159-170 with r eliminated: chord = 2 r sin(w/2) = v sinc(w/2))
@@ -199,6 +222,13 @@ __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float
 // ------------------------------------------------------------------------------------ fast path
 // Advances one world in float32.  Returns true when a margin falls inside the knife-edge band
 // (the caller then overrides pose/reward/term with exact_step()).
+//
+// Collision is decided from ONE running minimum of signed margins: the border margin
+// min(x, y) - 2.5, 97.5 - max(x, y) (aqua.py:424-427) and, per obstacle, m = (d^2 - R^2) / (2R) with d the
+// distance from the boat centre to the obstacle's box (aqua.py:373-390, 429-439).  m has exactly the sign
+// of d - R and |m| >= |d - R| / 2, so outside the band the sign of the minimum IS the reference's
+// OR-of-tests, and the strict/non-strict difference of the reference's comparisons only matters at
+// margin == 0, which is inside the band by construction.  ~10 VALU operations per obstacle, no compares.
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
                                           const StepConst& k, float& reward, uint32_t& term)
 {
@@ -209,23 +239,17 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float xn = e.x + ddx, yn = e.y + ddy;
     const float thn = wrap_add(e.th, w);
     // wave random walk (aqua.py:188-191): drawn after the move
-    const float wxn = fminf(fmaxf(fmaf(u0, k.sigma, e.wx), -k.W), k.W);
-    const float wyn = fminf(fmaxf(fmaf(u1, k.sigma, e.wy), -k.W), k.W);
+    const float wxn = __builtin_amdgcn_fmed3f(fmaf(u0, k.sigma, e.wx), -k.W, k.W);
+    const float wyn = __builtin_amdgcn_fmed3f(fmaf(u1, k.sigma, e.wy), -k.W, k.W);
     const int tn = e.t + 1;                                // aqua.py:141
 
-    // border (aqua.py:424-427, strict): margin < 0 <=> collided
-    const float mb = fminf(fminf(xn - 2.5f, yn - 2.5f), fminf(97.5f - xn, 97.5f - yn));
-    bool hit = mb < 0.0f;
-    bool knife = fabsf(mb) < BAND;
-    // obstacles (aqua.py:429-439): squared distance to the clamp box against bracketing thresholds
+    float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
+#pragma unroll 2
     for (int j = 0; j < k.K; ++j) {
-        const float4 box = *reinterpret_cast<const float4*>(&k.obst[j].lox);
-        const float2 thr = *reinterpret_cast<const float2*>(&k.obst[j].lo2);
-        const float dx = xn - fminf(fmaxf(xn, box.x), box.z);
-        const float dy = yn - fminf(fmaxf(yn, box.y), box.w);
+        const float dx = fmaxf(fabsf(xn - k.obst[j].cx) - k.obst[j].hx, 0.0f);
+        const float dy = fmaxf(fabsf(yn - k.obst[j].cy) - k.obst[j].hy, 0.0f);
         const float d2 = fmaf(dx, dx, dy * dy);
-        hit |= d2 <= thr.x;
-        knife |= (d2 > thr.x) & (d2 < thr.y);
+        mc = fminf(mc, fmaf(d2, k.obst[j].a, k.obst[j].b));
     }
     // goal distance and shaped reward (aqua.py:89-90, 392-402, 421-422).  prev - cur is formed
     // from the displacement, (|a|^2 - |b|^2) / (|a| + |b|), not as a difference of two norms.
@@ -234,12 +258,12 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float dprev = __builtin_amdgcn_sqrtf(fmaf(ex, ex, ey * ey));       // v_sqrt_f32, 1 ulp
     const float dcur = __builtin_amdgcn_sqrtf(fmaf(fx, fx, fy * fy));
     const float mg = dcur - 5.0f;
-    knife |= fabsf(mg) < BAND;
     const float dsum = dprev + dcur;
     const float num = fmaf(ddx, ex + fx, ddy * (ey + fy));
     const float shaped = dsum > 0.0f ? 0.7f * (num * __builtin_amdgcn_rcpf(dsum)) : 0.0f;
 
-    term = hit ? 1u : (tn > k.time_limit ? 2u : (mg <= 0.0f ? 3u : 0u));   // aqua.py:200-211
+    const bool knife = fminf(fabsf(mc), fabsf(mg)) < BAND;
+    term = mc < 0.0f ? 1u : (tn > k.time_limit ? 2u : (mg <= 0.0f ? 3u : 0u));   // aqua.py:200-211
     reward = term == 0u ? shaped : (term == 3u ? 10.0f : -10.0f);
     e.x = xn; e.y = yn; e.th = thn; e.wx = wxn; e.wy = wyn; e.t = tn;
     return knife;
@@ -248,14 +272,14 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
 // ------------------------------------------------------------------------------------ reset
 // float32 specification shared with nothing: oracle/aqua_oracle.c restates it independently and the
 // two are compared bit for bit.  Every rounding is explicit (fmaf or one operation per statement).
-__device__ __forceinline__ bool reset_hit(int K, const ObstF* __restrict__ t, float px, float py)
+__device__ __forceinline__ bool reset_hit(int K, ObstPtr t, float px, float py)
 {
 #pragma clang fp contract(off)
     bool hit = false;
+#pragma unroll 4
     for (int j = 0; j < K; ++j) {
-        const float qx = fminf(fmaxf(px, t[j].lox), t[j].hix);
-        const float qy = fminf(fmaxf(py, t[j].loy), t[j].hiy);
-        const float dx = px - qx, dy = py - qy;
+        const float ax = fabsf(px - t[j].cx), ay = fabsf(py - t[j].cy);
+        const float dx = fmaxf(ax - t[j].hx, 0.0f), dy = fmaxf(ay - t[j].hy, 0.0f);
         const float dy2 = dy * dy;
         const float d2 = fmaf(dx, dx, dy2);
         hit |= d2 <= t[j].r2;
@@ -264,7 +288,7 @@ __device__ __forceinline__ bool reset_hit(int K, const ObstF* __restrict__ t, fl
 }
 
 __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t tick, int waves, int random_boat,
-                                           int random_goal, int K, const ObstF* __restrict__ t)
+                                           int random_goal, int K, ObstPtr t)
 {
 #pragma clang fp contract(off)
     EnvState e;
@@ -301,6 +325,70 @@ __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t
     e.wx = W * u_pm1(r[0]);
     e.wy = W * u_pm1(r[1]);
     e.t = 0;                                               // aqua.py:125
+    return e;
+}
+
+// The same specification with the attempts of ONE world spread over a group of G adjacent lanes:
+// lane `sub` of the group evaluates attempts sub, sub + G, ... and the group keeps the lowest accepted
+// attempt (ballot + find-first), which is exactly the attempt the serial loop above stops at.  The
+// three Philox chains (goal, boat, wave) of the first round are independent and interleave.  Must be
+// called by all 64 lanes of a wavefront together; `active` says whether this lane's group has a world.
+// Every lane of a group returns the group's result.
+template <int G>
+__device__ __noinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
+                                                     int random_boat, int random_goal, int K, ObstPtr t)
+{
+#pragma clang fp contract(off)
+    static_assert(G >= 2 && G <= 64 && (G & (G - 1)) == 0, "group size");
+    constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int sub = lane & (G - 1), gbase = lane & ~(G - 1);
+    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    uint32_t rg[4], rb[4], rw[4];
+    draw(seed, env, tick, STREAM_GOAL, static_cast<uint32_t>(sub), rg);
+    draw(seed, env, tick, STREAM_BOAT, static_cast<uint32_t>(sub), rb);
+    draw(seed, env, tick, STREAM_WAVE, 0, rw);
+
+    float gx = 25.0f, gy = 80.0f;
+    if (random_goal) {
+        bool found = !active;
+        for (uint32_t base = 0; base < RESET_TRIES; base += G) {
+            if (base != 0) draw(seed, env, tick, STREAM_GOAL, base + sub, rg);
+            const float cx = fmaf(95.0f, u_01(rg[0]), 2.5f);
+            const float cy = fmaf(95.0f, u_01(rg[1]), 2.5f);
+            const bool ok = !found && !reset_hit(K, t, cx, cy);
+            const uint64_t mine = (__ballot(ok) >> gbase) & gmask;
+            const int src = mine ? gbase + __builtin_ctzll(mine) : lane;
+            const float sx = __shfl(cx, src), sy = __shfl(cy, src);
+            if (!found && mine) { gx = sx; gy = sy; found = true; }
+            if (!__any(!found)) break;
+        }
+    }
+    float bx = 85.0f, by = 45.0f, bt = 0.0f;
+    if (random_boat) {
+        bool found = !active;
+        for (uint32_t base = 0; base < RESET_TRIES; base += G) {
+            if (base != 0) draw(seed, env, tick, STREAM_BOAT, base + sub, rb);
+            const float cx = fmaf(95.0f, u_01(rb[0]), 2.5f);
+            const float cy = fmaf(95.0f, u_01(rb[1]), 2.5f);
+            const float ct = fmaf(TWO_PI_F, u_01(rb[2]), -PI_F);
+            const float ex = gx - cx, ey = gy - cy;
+            const float ey2 = ey * ey;
+            const float g2 = fmaf(ex, ex, ey2);
+            const bool ok = !found && !(g2 <= 25.0f) && !reset_hit(K, t, cx, cy);
+            const uint64_t mine = (__ballot(ok) >> gbase) & gmask;
+            const int src = mine ? gbase + __builtin_ctzll(mine) : lane;
+            const float sx = __shfl(cx, src), sy = __shfl(cy, src), st = __shfl(ct, src);
+            if (!found && mine) { bx = sx; by = sy; bt = st; found = true; }
+            if (!__any(!found)) break;
+        }
+    }
+    const float W = 0.05f * static_cast<float>(waves);
+    EnvState e;
+    e.x = bx; e.y = by; e.th = bt; e.gx = gx; e.gy = gy;
+    e.wx = W * u_pm1(rw[0]);
+    e.wy = W * u_pm1(rw[1]);
+    e.t = 0;
     return e;
 }
 

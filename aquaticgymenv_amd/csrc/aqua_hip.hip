@@ -25,8 +25,16 @@ using namespace aqua;
 
 namespace {
 
-constexpr int BLOCK = 256;
-constexpr int MAX_GRID = 256 * 8;        // 256 CUs x 8 workgroups: grid-stride beyond that
+#ifndef AQUA_TILE
+#define AQUA_TILE 1024                   // worlds per workgroup tile of the step kernel
+#endif
+constexpr int TILE_WORLDS = AQUA_TILE;   // step kernel: workgroup of TILE_WORLDS / VEC lanes
+constexpr int BLOCK_SMALL = 256;         // reset / fused-rollout kernels
+#ifndef AQUA_RESET_GROUP
+#define AQUA_RESET_GROUP 8               // lanes that share the re-seeding attempts of one finished world
+#endif
+constexpr int RESET_GROUP = AQUA_RESET_GROUP;
+constexpr int MAX_GRID = 1 << 30;        // step kernel: one workgroup per tile, no grid-stride loop
 
 struct StepArgs {
     float* state;
@@ -50,46 +58,44 @@ struct StepArgs {
 };
 
 // ------------------------------------------------------------------ vector load/store helpers
-template <int VEC> struct VecF;
-template <> struct VecF<1> { using type = float; };
-template <> struct VecF<2> { using type = float2; };
-template <> struct VecF<4> { using type = float4; };
-
-template <int VEC, typename T>
-__device__ __forceinline__ void load_row(const T* __restrict__ p, int64_t i0, int64_t n, T (&v)[VEC])
+// `p` is a wave-uniform row pointer already advanced to the tile, `off` the lane's element offset
+// inside the tile (32-bit), `rem` the number of valid elements from p on.  FULL tiles carry no guards:
+// the loads of a lane are issued back to back as global_load_dword{,x2,x4} v, voffset, s[base].
+template <int VEC, bool FULL, typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, int64_t rem, T (&v)[VEC])
 {
-    if constexpr (VEC == 1) {
-        v[0] = i0 < n ? p[i0] : T(0);
-    } else {
-        if (i0 + VEC <= n) {
+    if constexpr (FULL) {
+        if constexpr (VEC == 1) {
+            v[0] = p[off];
+        } else {
             struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
-            const Pack q = *reinterpret_cast<const Pack*>(p + i0);
+            const Pack q = *reinterpret_cast<const Pack*>(p + off);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j] = q.e[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) v[j] = (i0 + j < n) ? p[i0 + j] : T(0);
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = (static_cast<int64_t>(off) + j < rem) ? p[off + j] : T(0);
     }
 }
 
-template <int VEC, typename T>
-__device__ __forceinline__ void store_row(T* __restrict__ p, int64_t i0, int64_t n, const T (&v)[VEC])
+template <int VEC, bool FULL, typename T>
+__device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64_t rem, const T (&v)[VEC])
 {
-    if constexpr (VEC == 1) {
-        if (i0 < n) p[i0] = v[0];
-    } else {
-        if (i0 + VEC <= n) {
+    if constexpr (FULL) {
+        if constexpr (VEC == 1) {
+            p[off] = v[0];
+        } else {
             struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
             Pack q;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) q.e[j] = v[j];
-            *reinterpret_cast<Pack*>(p + i0) = q;
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                if (i0 + j < n) p[i0 + j] = v[j];
+            *reinterpret_cast<Pack*>(p + off) = q;
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (static_cast<int64_t>(off) + j < rem) p[off + j] = v[j];
     }
 }
 
@@ -118,19 +124,29 @@ __device__ __forceinline__ uint64_t spread_bits(uint64_t x)
     return 0;
 }
 
-__device__ __forceinline__ void stage_obstacles(ObstF* s_obst, const void* blob, int K)
+#if AQUA_OBST_LDS
+#define AQUA_OBST_DECL __shared__ ObstF s_obst[MAX_OBST];
+__device__ __forceinline__ ObstPtr stage_obstacles(ObstF* s_obst, const void* blob, int K)
 {
     const float4* src = reinterpret_cast<const float4*>(blob);
     float4* dst = reinterpret_cast<float4*>(s_obst);
-    for (int i = threadIdx.x; i < 2 * K; i += BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
+    return s_obst;
 }
+#else
+#define AQUA_OBST_DECL ObstF* s_obst = nullptr;
+__device__ __forceinline__ ObstPtr stage_obstacles(ObstF*, const void* blob, int)
+{
+    return (ObstPtr)(uintptr_t)blob;     // rows are read with scalar loads from the constant address space
+}
+#endif
 
-__device__ __forceinline__ StepConst make_const(const StepArgs& a, const ObstF* s_obst)
+__device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
 {
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K;
-    k.obst = s_obst;
+    k.obst = obst;
     k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstF) * a.K);
     return k;
 }
@@ -180,159 +196,244 @@ __device__ __forceinline__ int sample_discrete(uint32_t r) { return static_cast<
 __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u_01(r), 0.2f); }
 
 // ------------------------------------------------------------------ one launch per step
-template <int VEC, int AK>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const StepArgs a)
+// Workgroup = TILE_WORLDS / VEC lanes, tile = TILE_WORLDS consecutive worlds.  Worlds that finish are
+// not re-seeded by their own lane (that would be 1-2 active lanes per wavefront, in every wavefront,
+// looping over rejection attempts): their tile-local indices are appended to a list in LDS and, after
+// one barrier, groups of RESET_GROUP lanes re-seed them densely (reset_env_group) and write the fresh
+// state straight to HBM; the owning lane then skips its state store for that world.  One workgroup
+// per tile (no grid-stride loop: nothing loop-invariant to hoist, which keeps the SGPR file unspilled).
+struct TileShared {
+    uint32_t count;
+    uint16_t list[TILE_WORLDS];
+};
+
+// Philox draws of the lane's worlds (pairs share a call: see STREAM_STEP in aqua_device.hpp)
+template <int VEC, bool SCALAR_KEY = true>
+__device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream,
+                                           uint32_t (&w0)[VEC], uint32_t (&w1)[VEC])
 {
-    __shared__ ObstF s_obst[MAX_OBST];
-    stage_obstacles(s_obst, a.obst_blob, a.K);
-    const StepConst k = make_const(a, s_obst);
-    const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
-    const int64_t N = a.N, ld = a.ld;
-    const int64_t n_items = (N + VEC - 1) / VEC;
+    if constexpr (VEC == 1) {
+        uint32_t r[4];
+        draw<SCALAR_KEY>(seed, env0 >> 1, tick, stream, 0, r);
+        const bool odd = (env0 & 1u) != 0;
+        w0[0] = odd ? r[2] : r[0];
+        w1[0] = odd ? r[3] : r[1];
+    } else {
+#pragma unroll
+        for (int p = 0; p < VEC / 2; ++p) {             // env0 is even for VEC >= 2 (checked on the host)
+            uint32_t r[4];
+            draw<SCALAR_KEY>(seed, (env0 >> 1) + p, tick, stream, 0, r);
+            w0[2 * p] = r[0]; w1[2 * p] = r[1];
+            w0[2 * p + 1] = r[2]; w1[2 * p + 1] = r[3];
+        }
+    }
+}
+
+template <int VEC, int AK, bool FULL>
+__device__ __forceinline__ void load_inputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, float (&x)[VEC],
+                                            float (&y)[VEC], float (&th)[VEC], float (&gx)[VEC], float (&gy)[VEC],
+                                            float (&wx)[VEC], float (&wy)[VEC], int32_t (&t)[VEC], int (&aidx)[VEC],
+                                            float (&avl)[VEC], float (&avr)[VEC], float (&u0)[VEC], float (&u1)[VEC])
+{
+    const int64_t ld = a.ld;
+    const float* const row0 = a.state + tile;
+    load_row<VEC, FULL>(row0 + 0 * ld, off, rem, x);
+    load_row<VEC, FULL>(row0 + 1 * ld, off, rem, y);
+    load_row<VEC, FULL>(row0 + 2 * ld, off, rem, th);
+    load_row<VEC, FULL>(row0 + 3 * ld, off, rem, gx);
+    load_row<VEC, FULL>(row0 + 4 * ld, off, rem, gy);
+    load_row<VEC, FULL>(row0 + 5 * ld, off, rem, wx);
+    load_row<VEC, FULL>(row0 + 6 * ld, off, rem, wy);
+    load_row<VEC, FULL>(a.time + tile, off, rem, t);
+    if constexpr (AK == AQUA_ACT_U8) {
+        uint8_t v[VEC];
+        load_row<VEC, FULL>(static_cast<const uint8_t*>(a.action) + tile, off, rem, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) aidx[j] = v[j] > 2 ? 2 : v[j];
+    } else if constexpr (AK == AQUA_ACT_I32) {
+        int32_t v[VEC];
+        load_row<VEC, FULL>(static_cast<const int32_t*>(a.action) + tile, off, rem, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) aidx[j] = fold_index(v[j]);
+    } else if constexpr (AK == AQUA_ACT_I64) {
+        int64_t v[VEC];
+        load_row<VEC, FULL>(static_cast<const int64_t*>(a.action) + tile, off, rem, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) aidx[j] = fold_index(v[j]);
+    } else if constexpr (AK == AQUA_ACT_F32X2) {
+        load_row<VEC, FULL>(static_cast<const float*>(a.action) + tile, off, rem, avl);
+        load_row<VEC, FULL>(static_cast<const float*>(a.action) + a.action_ld + tile, off, rem, avr);
+    }
+    if (a.noise != nullptr) {
+        load_row<VEC, FULL>(a.noise + tile, off, rem, u0);
+        load_row<VEC, FULL>(a.noise + a.noise_ld + tile, off, rem, u1);
+    }
+}
+
+template <int VEC, int AK>
+__device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
+                                          TileShared& sh)
+{
+    constexpr int BLOCK = TILE_WORLDS / VEC;
+    const int64_t ld = a.ld;
+    const int64_t rem = a.N - tile;                      // > 0, uniform
+    const uint32_t off = threadIdx.x * VEC;
     const int lane = threadIdx.x & 63;
-    const int64_t n_words = (N + 63) >> 6;
+    float* const row0 = a.state + tile;                  // uniform row pointers (SGPR pairs)
+    int32_t* const trow = a.time + tile;
 
-    for (int64_t wave_item = (static_cast<int64_t>(blockIdx.x) * BLOCK + (threadIdx.x & ~63)); wave_item < n_items;
-         wave_item += static_cast<int64_t>(gridDim.x) * BLOCK) {
-        const int64_t i0 = (wave_item + lane) * VEC;
+    float x[VEC], y[VEC], th[VEC], gx[VEC], gy[VEC], wx[VEC], wy[VEC], u0[VEC], u1[VEC], avl[VEC], avr[VEC];
+    int32_t t[VEC];
+    int aidx[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { aidx[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; u0[j] = 0.0f; u1[j] = 0.0f; }
+    const bool full = rem >= TILE_WORLDS;                // uniform: a whole tile carries no per-lane guards
+    if (full) load_inputs<VEC, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
+    else load_inputs<VEC, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
 
-        float x[VEC], y[VEC], th[VEC], gx[VEC], gy[VEC], wx[VEC], wy[VEC];
-        int32_t t[VEC];
-        load_row<VEC>(a.state + 0 * ld, i0, N, x);
-        load_row<VEC>(a.state + 1 * ld, i0, N, y);
-        load_row<VEC>(a.state + 2 * ld, i0, N, th);
-        load_row<VEC>(a.state + 3 * ld, i0, N, gx);
-        load_row<VEC>(a.state + 4 * ld, i0, N, gy);
-        load_row<VEC>(a.state + 5 * ld, i0, N, wx);
-        load_row<VEC>(a.state + 6 * ld, i0, N, wy);
-        load_row<VEC>(a.time, i0, N, t);
-
-        int aidx[VEC];
-        float avl[VEC], avr[VEC];
+    const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
+    if (a.noise == nullptr) {
+        uint32_t w0[VEC], w1[VEC];
+        pair_draws<VEC>(a.seed, env0, tick, STREAM_STEP, w0, w1);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { aidx[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; }
-        if constexpr (AK == AQUA_ACT_U8) {
-            uint8_t v[VEC];
-            load_row<VEC>(static_cast<const uint8_t*>(a.action), i0, N, v);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) aidx[j] = fold_index(v[j]);
-        } else if constexpr (AK == AQUA_ACT_I32) {
-            int32_t v[VEC];
-            load_row<VEC>(static_cast<const int32_t*>(a.action), i0, N, v);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) aidx[j] = fold_index(v[j]);
-        } else if constexpr (AK == AQUA_ACT_I64) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                aidx[j] = fold_index((i0 + j < N) ? static_cast<const int64_t*>(a.action)[i0 + j] : 2);
-        } else if constexpr (AK == AQUA_ACT_F32X2) {
-            load_row<VEC>(static_cast<const float*>(a.action), i0, N, avl);
-            load_row<VEC>(static_cast<const float*>(a.action) + a.action_ld, i0, N, avr);
-        }
-
-        float u0[VEC], u1[VEC];
-        if (a.noise != nullptr) {
-            load_row<VEC>(a.noise, i0, N, u0);
-            load_row<VEC>(a.noise + a.noise_ld, i0, N, u1);
-        }
-        if (a.noise == nullptr || AK >= AQUA_ACT_SAMPLE_D) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                uint32_t r[4];
-                draw(a.seed, static_cast<uint64_t>(a.env_offset + i0 + j), tick, STREAM_STEP, 0, r);
-                if (a.noise == nullptr) { u0[j] = u_pm1(r[0]); u1[j] = u_pm1(r[1]); }
-                if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[j] = sample_discrete(r[2]);
-                if constexpr (AK == AQUA_ACT_SAMPLE_C) { avl[j] = sample_thrust(r[2]); avr[j] = sample_thrust(r[3]); }
-            }
-        }
-
-        float rew[VEC];
-        uint8_t code[VEC];
-        Motion mo[VEC];
-        uint32_t knife_mask = 0, done_mask = 0;
+        for (int j = 0; j < VEC; ++j) { u0[j] = u_pm1(w0[j]); u1[j] = u_pm1(w1[j]); }
+    }
+    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+        uint32_t w0[VEC], w1[VEC];
+        pair_draws<VEC, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            EnvState e{x[j], y[j], th[j], gx[j], gy[j], wx[j], wy[j], t[j]};
-            mo[j] = decode_motion<AK>(k, aidx[j], avl[j], avr[j]);
-            uint32_t c;
-            const bool knife = fast_step(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
-            const bool valid = i0 + j < N;
-            knife_mask |= (knife && valid) ? (1u << j) : 0u;
-            code[j] = static_cast<uint8_t>(c);
-            x[j] = e.x; y[j] = e.y; th[j] = e.th; wx[j] = e.wx; wy[j] = e.wy; t[j] = e.t;
+            if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[j] = sample_discrete(w0[j]);
+            else { avl[j] = sample_thrust(w0[j]); avr[j] = sample_thrust(w1[j]); }
         }
-        // knife-edge worlds: redo pose, reward and termination in float64 from the inputs still in memory
-        if (__any(knife_mask != 0)) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                if (knife_mask & (1u << j)) {
-                    const int64_t i = i0 + j;
-                    double vl, vr;
-                    exact_thrusts<AK>(mo[j], vl, vr);
-                    const ExactOut o = exact_step(a.state[0 * ld + i], a.state[1 * ld + i], a.state[2 * ld + i], gx[j],
-                                                  gy[j], a.state[5 * ld + i], a.state[6 * ld + i], t[j], vl, vr, k.K,
-                                                  k.obst64, k.time_limit);
-                    x[j] = o.x; y[j] = o.y; th[j] = o.th; rew[j] = o.reward; code[j] = static_cast<uint8_t>(o.term);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) done_mask |= (code[j] != 0 && i0 + j < N) ? (1u << j) : 0u;
-
-        // outputs of the step that just happened
-        store_row<VEC>(a.reward, i0, N, rew);
-        store_row<VEC>(a.term, i0, N, code);
-        if (a.done_bits != nullptr) {
-            uint64_t mine = 0;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const uint64_t b = __ballot((done_mask >> j) & 1u);
-#pragma unroll
-                for (int wq = 0; wq < VEC; ++wq) {
-                    const uint64_t piece = spread_bits<VEC>(b >> (wq * (64 / VEC))) << j;
-                    if (lane == wq) mine |= piece;
-                }
-            }
-            const int64_t word = (wave_item / 64) * VEC + lane;
-            if (lane < VEC && word < n_words) a.done_bits[word] = mine;
-        }
-
-        // finished worlds start a new episode inside the same launch
-        if (a.auto_reset && __any(done_mask != 0)) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                if (done_mask & (1u << j)) {
-                    const EnvState e = reset_env(a.seed, static_cast<uint64_t>(a.env_offset + i0 + j), tick, k.waves,
-                                                 a.random_boat, a.random_goal, k.K, k.obst);
-                    x[j] = e.x; y[j] = e.y; th[j] = e.th; gx[j] = e.gx; gy[j] = e.gy; wx[j] = e.wx; wy[j] = e.wy;
-                    t[j] = e.t;
-                }
-            }
-            if (done_mask != 0) {
-                store_row<VEC>(a.state + 3 * ld, i0, N, gx);
-                store_row<VEC>(a.state + 4 * ld, i0, N, gy);
-            }
-        }
-        store_row<VEC>(a.state + 0 * ld, i0, N, x);
-        store_row<VEC>(a.state + 1 * ld, i0, N, y);
-        store_row<VEC>(a.state + 2 * ld, i0, N, th);
-        store_row<VEC>(a.state + 5 * ld, i0, N, wx);
-        store_row<VEC>(a.state + 6 * ld, i0, N, wy);
-        store_row<VEC>(a.time, i0, N, t);
     }
+
+    float rew[VEC];
+    uint8_t code[VEC];
+    Motion mo[VEC];
+    uint32_t knife_mask = 0, done_mask = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        EnvState e{x[j], y[j], th[j], gx[j], gy[j], wx[j], wy[j], t[j]};
+        mo[j] = decode_motion<AK>(k, aidx[j], avl[j], avr[j]);
+        uint32_t c;
+        const bool knife = fast_step(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
+        const bool valid = static_cast<int64_t>(off) + j < rem;
+        knife_mask |= (knife && valid) ? (1u << j) : 0u;
+        code[j] = static_cast<uint8_t>(c);
+        x[j] = e.x; y[j] = e.y; th[j] = e.th; wx[j] = e.wx; wy[j] = e.wy; t[j] = e.t;
+    }
+    // knife-edge worlds: redo pose, reward and termination in float64 from the inputs still in memory
+    if (__any(knife_mask != 0)) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (knife_mask & (1u << j)) {
+                const uint32_t i = off + j;
+                double vl, vr;
+                exact_thrusts<AK>(mo[j], vl, vr);
+                const ExactOut o = exact_step(row0[0 * ld + i], row0[1 * ld + i], row0[2 * ld + i], gx[j], gy[j],
+                                              row0[5 * ld + i], row0[6 * ld + i], t[j], vl, vr, k.K, k.obst64,
+                                              k.time_limit);
+                x[j] = o.x; y[j] = o.y; th[j] = o.th; rew[j] = o.reward; code[j] = static_cast<uint8_t>(o.term);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+        done_mask |= (code[j] != 0 && static_cast<int64_t>(off) + j < rem) ? (1u << j) : 0u;
+
+    // outputs of the step that just happened
+    if (full) {
+        store_row<VEC, true>(a.reward + tile, off, rem, rew);
+        store_row<VEC, true>(a.term + tile, off, rem, code);
+    } else {
+        store_row<VEC, false>(a.reward + tile, off, rem, rew);
+        store_row<VEC, false>(a.term + tile, off, rem, code);
+    }
+    if (a.done_bits != nullptr) {
+        uint64_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint64_t b = __ballot((done_mask >> j) & 1u);
+#pragma unroll
+            for (int wq = 0; wq < VEC; ++wq) {
+                const uint64_t piece = spread_bits<VEC>(b >> (wq * (64 / VEC))) << j;
+                if (lane == wq) mine |= piece;
+            }
+        }
+        const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u) * VEC) / 64 + lane;
+        if (lane < VEC && word < ((a.N + 63) >> 6)) a.done_bits[word] = mine;
+    }
+
+    uint32_t skip_mask = 0;        // worlds whose state is written by a re-seeding group instead
+    if (a.auto_reset) {
+        uint32_t* const cnt = &sh.count;
+        uint16_t* const list = sh.list;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (done_mask & (1u << j)) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off + j);
+        }
+        skip_mask = done_mask;
+        __syncthreads();
+        const uint32_t n_done = *cnt;
+        constexpr uint32_t GROUPS = BLOCK / RESET_GROUP;
+        const uint32_t wave_first_group = (threadIdx.x & ~63u) / RESET_GROUP;
+        for (uint32_t qb = wave_first_group; qb < n_done; qb += GROUPS) {
+            const uint32_t q = qb + (lane / RESET_GROUP);
+            const bool active = q < n_done;
+            const uint32_t i = list[active ? q : 0];
+            const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
+                                                            tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                row0[0 * ld + i] = e.x; row0[1 * ld + i] = e.y; row0[2 * ld + i] = e.th;
+                row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
+                row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
+                trow[i] = e.t;
+            }
+        }
+    }
+    if (skip_mask == 0 && full) {
+        store_row<VEC, true>(row0 + 0 * ld, off, rem, x);
+        store_row<VEC, true>(row0 + 1 * ld, off, rem, y);
+        store_row<VEC, true>(row0 + 2 * ld, off, rem, th);
+        store_row<VEC, true>(row0 + 5 * ld, off, rem, wx);
+        store_row<VEC, true>(row0 + 6 * ld, off, rem, wy);
+        store_row<VEC, true>(trow, off, rem, t);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t i = off + j;
+            if (!(skip_mask & (1u << j)) && static_cast<int64_t>(i) < rem) {
+                row0[0 * ld + i] = x[j]; row0[1 * ld + i] = y[j]; row0[2 * ld + i] = th[j];
+                row0[5 * ld + i] = wx[j]; row0[6 * ld + i] = wy[j];
+                trow[i] = t[j];
+            }
+        }
+    }
+}
+
+template <int VEC, int AK>
+__global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs a)
+{
+    AQUA_OBST_DECL
+    __shared__ TileShared sh;
+    if (threadIdx.x == 0) sh.count = 0;
+    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    if (a.auto_reset) __syncthreads();
+    const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
+    step_tile<VEC, AK>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
 // ------------------------------------------------------------------ T steps in one launch
 template <int AK>
-__global__ __launch_bounds__(BLOCK) void rollout_kernel(const StepArgs a)
+__global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
 {
-    __shared__ ObstF s_obst[MAX_OBST];
-    stage_obstacles(s_obst, a.obst_blob, a.K);
-    const StepConst k = make_const(a, s_obst);
+    AQUA_OBST_DECL
+    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick0 = a.tick + (a.tick_base ? *a.tick_base : 0ull);
     const int64_t N = a.N, ld = a.ld;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < N;
-         i += static_cast<int64_t>(gridDim.x) * BLOCK) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
+         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
         EnvState e{a.state[0 * ld + i], a.state[1 * ld + i], a.state[2 * ld + i], a.state[3 * ld + i],
                    a.state[4 * ld + i], a.state[5 * ld + i], a.state[6 * ld + i], a.time[i]};
         const uint64_t env = static_cast<uint64_t>(a.env_offset + i);
@@ -347,11 +448,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const StepArgs a)
                 const float* base = static_cast<const float*>(a.action) + s * a.action_step_stride;
                 vl = base[i]; vr = base[a.action_ld + i];
             }
-            uint32_t r[4];
-            draw(a.seed, env, tick, STREAM_STEP, 0, r);
-            const float u0 = u_pm1(r[0]), u1 = u_pm1(r[1]);
-            if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(r[2]);
-            if constexpr (AK == AQUA_ACT_SAMPLE_C) { vl = sample_thrust(r[2]); vr = sample_thrust(r[3]); }
+            uint32_t w0[1], w1[1];
+            pair_draws<1, false>(a.seed, env, tick, STREAM_STEP, w0, w1);
+            const float u0 = u_pm1(w0[0]), u1 = u_pm1(w1[0]);
+            if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+                pair_draws<1, false>(a.seed, env, tick, STREAM_ACT, w0, w1);
+                if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(w0[0]);
+                else { vl = sample_thrust(w0[0]); vr = sample_thrust(w1[0]); }
+            }
             const Motion m = decode_motion<AK>(k, idx, vl, vr);
             const EnvState before = e;
             float rew;
@@ -380,17 +484,17 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const StepArgs a)
 }
 
 // ------------------------------------------------------------------ masked reset
-__global__ __launch_bounds__(BLOCK) void reset_kernel(const StepArgs a, const uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, const uint8_t* __restrict__ mask)
 {
-    __shared__ ObstF s_obst[MAX_OBST];
-    stage_obstacles(s_obst, a.obst_blob, a.K);
+    AQUA_OBST_DECL
+    const ObstPtr obst = stage_obstacles(s_obst, a.obst_blob, a.K);
     const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
     const int64_t N = a.N, ld = a.ld;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < N;
-         i += static_cast<int64_t>(gridDim.x) * BLOCK) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
+         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
         if (mask != nullptr && mask[i] == 0) continue;
         const EnvState e = reset_env(a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat,
-                                     a.random_goal, a.K, s_obst);
+                                     a.random_goal, a.K, obst);
         a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
         a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
         a.state[5 * ld + i] = e.wx; a.state[6 * ld + i] = e.wy;
@@ -421,11 +525,11 @@ int hip_fail(hipError_t e, const char* what)
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-int grid_for(int64_t items)
+int grid_for(int64_t items, int block, int max_grid)
 {
-    int64_t g = (items + BLOCK - 1) / BLOCK;
+    int64_t g = (items + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > MAX_GRID) g = MAX_GRID;
+    if (g > max_grid) g = max_grid;
     return static_cast<int>(g);
 }
 
@@ -462,15 +566,18 @@ size_t action_elem_bytes(int kind)
 }
 
 int pick_vec(const float* state, int64_t ld, const int32_t* time, const float* reward, const void* action,
-             int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld, const uint8_t* term, int64_t N)
+             int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld, const uint8_t* term, int64_t N,
+             int64_t env_offset)
 {
+    if (env_offset & 1) return 1;          // noise pairs (world >> 1) must not straddle lanes
     int want = g_vec_override.load();
-    if (want == 0) want = N >= 4 * BLOCK * 256 ? 4 : (N >= 2 * BLOCK * 256 ? 2 : 1);
+    if (want == 0) want = 1;            // measured fastest at every batch size (profiles/)
     for (int v = want; v > 1; v >>= 1) {
         bool ok = aligned(state, 4 * v) && aligned(time, 4 * v) && aligned(reward, 4 * v) && (ld % v == 0) &&
                   aligned(term, v);
         if (action_kind == AQUA_ACT_U8) ok = ok && aligned(action, v);
         if (action_kind == AQUA_ACT_I32) ok = ok && aligned(action, 4 * v);
+        if (action_kind == AQUA_ACT_I64) ok = ok && aligned(action, 8 * v);
         if (action_kind == AQUA_ACT_F32X2) ok = ok && aligned(action, 4 * v) && (action_ld % v == 0);
         if (noise != nullptr) ok = ok && aligned(noise, 4 * v) && (noise_ld % v == 0);
         if (ok) return v;
@@ -482,7 +589,8 @@ template <int VEC>
 hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
 {
     const int64_t items = (a.N + VEC - 1) / VEC;
-    const dim3 grid(grid_for(items)), block(BLOCK);
+    if ((a.N + TILE_WORLDS - 1) / TILE_WORLDS > MAX_GRID) return hipErrorInvalidValue;
+    const dim3 grid(grid_for(items, TILE_WORLDS / VEC, MAX_GRID)), block(TILE_WORLDS / VEC);
     switch (kind) {
         case AQUA_ACT_U8: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_U8>), grid, block, 0, s, a); break;
         case AQUA_ACT_I32: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_I32>), grid, block, 0, s, a); break;
@@ -545,17 +653,16 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
     if (blob_bytes < aqua_obstacle_blob_bytes(K)) return fail(AQUA_E_INVALID, "blob too small");
     ObstF* f = static_cast<ObstF*>(blob_host);
     double* d = reinterpret_cast<double*>(static_cast<char*>(blob_host) + sizeof(ObstF) * K);
-    const double band = static_cast<double>(BAND);
     for (int k = 0; k < K; ++k) {
         const double* o = rows + 5 * k;
         if (!(o[2] == 0.0 || o[2] == 1.0)) return fail(AQUA_E_INVALID, "obstacle %d: kind must be 0 or 1", k);
         double hx = 0, hy = 0, R = 2.5;                 // boat radius (aqua.py:75)
         if (o[2] == 0.0) R += o[3]; else { hx = o[3] / 2; hy = o[4] / 2; }
-        f[k].lox = static_cast<float>(o[0] - hx); f[k].hix = static_cast<float>(o[0] + hx);
-        f[k].loy = static_cast<float>(o[1] - hy); f[k].hiy = static_cast<float>(o[1] + hy);
-        const double lo = R - band > 0 ? R - band : 0.0;
-        f[k].lo2 = static_cast<float>(lo * lo);
-        f[k].hi2 = static_cast<float>((R + band) * (R + band));
+        if (!(R > 0.0) || hx < 0.0 || hy < 0.0) return fail(AQUA_E_INVALID, "obstacle %d: negative size", k);
+        f[k].cx = static_cast<float>(o[0]); f[k].cy = static_cast<float>(o[1]);
+        f[k].hx = static_cast<float>(hx); f[k].hy = static_cast<float>(hy);
+        f[k].a = static_cast<float>(1.0 / (2.0 * R));
+        f[k].b = static_cast<float>(-R / 2.0);
         f[k].r2 = static_cast<float>(R * R);
         f[k].pad = 0.0f;
         for (int j = 0; j < 5; ++j) d[5 * k + j] = o[j];
@@ -567,7 +674,7 @@ int aqua_step_vector_width(const float* state, int64_t ld, const int32_t* time, 
                            const void* action, int action_kind, int64_t action_ld, const float* noise,
                            int64_t noise_ld, const uint8_t* term)
 {
-    return pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, INT64_MAX);
+    return pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, INT64_MAX, 0);
 }
 
 void aqua_discrete_constants(float out[9])
@@ -598,7 +705,7 @@ int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t
     if (N == 0) return 0;
     a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
     a.reward = reward; a.term = term; a.done_bits = done_bits; a.auto_reset = auto_reset;
-    const int vec = pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, N);
+    const int vec = pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, N, env_offset);
     const hipError_t e = launch_step_any(a, action_kind, vec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_step_f32 launch");
 }
@@ -611,7 +718,7 @@ int aqua_reset_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_
     const int rc = fill_args(a, p, obst_blob_dev, K, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
     if (rc) return rc;
     if (N == 0) return 0;
-    hipLaunchKernelGGL(reset_kernel, dim3(grid_for(N)), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), a, mask);
+    hipLaunchKernelGGL(reset_kernel, dim3(grid_for(N, BLOCK_SMALL, 2048)), dim3(BLOCK_SMALL), 0, static_cast<hipStream_t>(stream), a, mask);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_reset_f32 launch");
 }
@@ -638,7 +745,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
         a.reward = reward + t * out_step_stride;
         a.term = term + t * out_step_stride;
         a.done_bits = done_bits ? done_bits + t * done_step_stride : nullptr;
-        const int vec = pick_vec(state, ld, time, a.reward, a.action, action_kind, action_ld, nullptr, 0, a.term, N);
+        const int vec = pick_vec(state, ld, time, a.reward, a.action, action_kind, action_ld, nullptr, 0, a.term, N, env_offset);
         const hipError_t e = launch_step_any(a, action_kind, vec, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "aqua_rollout_f32 launch");
     }
@@ -660,7 +767,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     if (N == 0 || T == 0) return 0;
     a.action = actions; a.action_ld = action_ld; a.action_step_stride = action_step_stride;
     a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;
-    const dim3 grid(grid_for(N)), block(BLOCK);
+    const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (action_kind) {
         case AQUA_ACT_U8: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_U8>), grid, block, 0, s, a); break;

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=262144, help="worlds per GPU")
     ap.add_argument("--continuous", action="store_true", help="configs[3]: continuous actions")
     ap.add_argument("--no-obstacles", action="store_true", help="configs[1]-style: no obstacles")
+    ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: finished worlds are not restarted")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
@@ -115,7 +116,7 @@ def main():
     n = args.envs
     obstacles = presets.NONE if args.no_obstacles else presets.BENCH8
     env = BatchedAqua(n, obstacles=obstacles, continuous=args.continuous, seed=0, env_offset=rank * n,
-                      auto_reset=True, device=dev)
+                      auto_reset=not args.no_auto_reset, device=dev)
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     if args.continuous:
@@ -156,7 +157,7 @@ def main():
 
     # sanity on the timed work: worlds did move and episodes did end (no cached / skipped work)
     ended = int((hist[0].cpu().numpy().view(np.uint64) != 0).sum())
-    assert env._tick >= args.steps + args.warmup and ended > 0
+    assert env._tick >= args.steps + args.warmup and (ended > 0 or args.no_auto_reset)
 
     result = None
     if rank == 0:

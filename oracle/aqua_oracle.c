@@ -58,7 +58,7 @@ void aqua_oracle_philox(uint32_t k0, uint32_t k1, const uint32_t ctr[4], uint32_
 }
 
 /* stream ids of this build's RNG specification (DESIGN.md "RNG") */
-enum { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3 };
+enum { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3, STREAM_ACT = 4 };
 
 static inline void aqua_draw(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, uint32_t attempt,
                              uint32_t out[4])
@@ -75,11 +75,28 @@ static inline void aqua_draw(uint64_t seed, uint64_t env, uint64_t tick, uint32_
 static inline double u_pm1(uint32_t r) { return (double)(r >> 8) * 0x1p-23 - 1.0; }   /* [-1, 1) */
 static inline float u01f(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }            /* [0, 1)  */
 
+/*
+ * Step noise of world `env` at `tick`: one Philox call serves the PAIR of worlds (env >> 1); the even
+ * world takes words 0,1 and the odd world words 2,3 (a lane that advances two worlds makes one call).
+ * raw[] returns the two words of this world (raw[0], raw[1]) for inspection.
+ */
 void aqua_oracle_step_noise(uint64_t seed, uint64_t env, uint64_t tick, double out_u[2], uint32_t raw[4])
 {
-    aqua_draw(seed, env, tick, STREAM_STEP, 0, raw);
-    out_u[0] = u_pm1(raw[0]);
-    out_u[1] = u_pm1(raw[1]);
+    uint32_t r[4];
+    aqua_draw(seed, env >> 1, tick, STREAM_STEP, 0, r);
+    const int h = (int)(env & 1u) * 2;
+    raw[0] = r[h]; raw[1] = r[h + 1]; raw[2] = 0; raw[3] = 0;
+    out_u[0] = u_pm1(r[h]);
+    out_u[1] = u_pm1(r[h + 1]);
+}
+
+/* the two action words of world `env` at `tick` (device-sampled actions of the synthetic rollouts) */
+static void action_words(uint64_t seed, uint64_t env, uint64_t tick, uint32_t out[2])
+{
+    uint32_t r[4];
+    aqua_draw(seed, env >> 1, tick, STREAM_ACT, 0, r);
+    const int h = (int)(env & 1u) * 2;
+    out[0] = r[h]; out[1] = r[h + 1];
 }
 
 /* ------------------------------------------------------- geometry, float64 */
@@ -246,7 +263,7 @@ void aqua_oracle_step(int64_t n, int K, const double* obst, int waves, double* s
  * [0, 100] gives the same distribution.  After 64 rejected attempts the fixed pose of
  * aqua.py:107,117 is used.
  */
-typedef struct { float lox, loy, hix, hiy, r2; } ObstF;
+typedef struct { float cx, cy, hx, hy, r2; } ObstF;     /* box centre + half extents (0 for a circle) */
 
 static void obst_to_f32(int K, const double* obst, double other_radius, ObstF* t)
 {
@@ -254,19 +271,19 @@ static void obst_to_f32(int K, const double* obst, double other_radius, ObstF* t
         const double* o = obst + 5 * k;
         double hx = 0, hy = 0, rs = other_radius;
         if (o[2] == 0.0) rs += o[3]; else { hx = o[3] / 2; hy = o[4] / 2; }
-        t[k].lox = (float)(o[0] - hx); t[k].hix = (float)(o[0] + hx);
-        t[k].loy = (float)(o[1] - hy); t[k].hiy = (float)(o[1] + hy);
+        t[k].cx = (float)o[0]; t[k].cy = (float)o[1];
+        t[k].hx = (float)hx; t[k].hy = (float)hy;
         t[k].r2 = (float)(rs * rs);
     }
 }
 
+/* distance from the point to the box, per axis max(|p - c| - h, 0); one rounding per operation */
 static int hit_f32(int K, const ObstF* t, float px, float py)
 {
     int hit = 0;
     for (int k = 0; k < K; ++k) {
-        float qx = fminf(fmaxf(px, t[k].lox), t[k].hix);
-        float qy = fminf(fmaxf(py, t[k].loy), t[k].hiy);
-        float dx = px - qx, dy = py - qy;
+        float ax = fabsf(px - t[k].cx), ay = fabsf(py - t[k].cy);
+        float dx = fmaxf(ax - t[k].hx, 0.0f), dy = fmaxf(ay - t[k].hy, 0.0f);
         float dy2 = dy * dy;
         float d2 = fmaf(dx, dx, dy2);
         hit |= (d2 <= t[k].r2);
@@ -331,7 +348,7 @@ void aqua_oracle_reset(int64_t n, int K, const double* obst, int waves, int rand
  * The batched build stores its state in float32.  This drives step_one() from float32 storage
  * (state widened exactly to float64, result rounded to float32) with Philox noise, on-spec action
  * sampling and auto-reset; it is the CPU baseline timed by bench.py and the multi-step checker.
- * actions == NULL -> actions are sampled from the step draw (raw[2], raw[3]) as the device
+ * actions == NULL -> actions are sampled from Philox stream 4 (action_words) as the device
  * rollout does.  Returns the number of finished episodes.
  */
 int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves, int continuous, float* state,
@@ -345,7 +362,7 @@ int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves,
 #pragma omp parallel for schedule(static) reduction(+ : episodes, c1, c2, c3)
         for (int64_t i = 0; i < n; ++i) {
             double s[7], u[2], vl, vr, rew;
-            uint32_t raw[4];
+            uint32_t raw[4], aw[2];
             uint8_t code;
             for (int j = 0; j < 7; ++j) s[j] = (double)state[j * ld + i];
             aqua_oracle_step_noise(seed, (uint64_t)(env_offset + i), tick, u, raw);
@@ -354,11 +371,13 @@ int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves,
                 const char* base = (const char*)actions + (size_t)t * (size_t)n * esz;
                 decode_action(action_kind, base, i, n, &vl, &vr);
             } else if (continuous) {
-                float fl = fmaf(0.3f, u01f(raw[2]), 0.2f), fr = fmaf(0.3f, u01f(raw[3]), 0.2f);
+                action_words(seed, (uint64_t)(env_offset + i), tick, aw);
+                float fl = fmaf(0.3f, u01f(aw[0]), 0.2f), fr = fmaf(0.3f, u01f(aw[1]), 0.2f);
                 vl = clipd((double)fl, 0.2, 0.5); vr = clipd((double)fr, 0.2, 0.5);
             } else {
                 static const double tab[3][2] = {{0.2, 0.5}, {0.5, 0.2}, {0.5, 0.5}};
-                uint32_t a = (uint32_t)(((uint64_t)(raw[2] >> 8) * 3u) >> 24);
+                action_words(seed, (uint64_t)(env_offset + i), tick, aw);
+                uint32_t a = (uint32_t)(((uint64_t)(aw[0] >> 8) * 3u) >> 24);
                 vl = tab[a][0]; vr = tab[a][1];
             }
             step_one(K, obst, waves, s, &time[i], vl, vr, u, &rew, &code, NULL);
