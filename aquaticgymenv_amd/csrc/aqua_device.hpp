@@ -19,15 +19,24 @@ constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band, i
 constexpr int RESET_TRIES = 64;
 constexpr int MAX_OBST = 64;
 
-// one obstacle in fast-path form: a box (a circle is a box with zero half extents) inflated by R
+// one obstacle in fast-path form: a box (a circle is a box with zero half extents) inflated by R.
+// The packed table lists the CIRCLES FIRST (header.n_circles of them): their per-axis distance needs no
+// |.| - h, max(., 0) (the generic formula with h = 0 gives the same bits).
 struct ObstF {
     float cx, cy, hx, hy;       // box centre and half extents (aqua.py:381-384); circle: hx = hy = 0
-    float a, b;                 // a = 1 / (2R), b = -R / 2 with R = obstacle radius + 2.5 (circle) or 2.5 (rect):
-                                //   m = a * d^2 + b = (d^2 - R^2) / (2R) has the sign of (d - R) and ~ its size near 0
-    float r2;                   // R^2, used by the float32 reset specification
-    float pad;
+    float r2;                   // R^2 with R = obstacle radius + 2.5 (circle) or 2.5 (rect)
+    float pad[3];
 };
 static_assert(sizeof(ObstF) == 32, "ObstF is two float4");
+
+// first 32 bytes of the packed blob
+struct ObstHeader {
+    int32_t n_obstacles, n_circles;
+    float band2;                // knife-edge band for the SQUARED margin d^2 - R^2: 2.5 * R_max * BAND
+    float r_max;
+    int32_t reserved[4];
+};
+static_assert(sizeof(ObstHeader) == 32, "ObstHeader");
 
 // Where the per-batch obstacle table is read from.  Default: straight from the packed blob through the
 // CONSTANT address space -- every lane reads the same row, so the loads are scalar (s_load_dwordx4 into
@@ -52,7 +61,8 @@ struct StepConst {              // wave-uniform
     float W, sigma;             // wave bound 0.05*waves, wave step 0.001*waves (aqua.py:23-25)
     int waves;
     int time_limit;             // aqua.py:91
-    int K;
+    int K, Kc;                  // obstacles, of which the first Kc are circles
+    float band2;
     ObstPtr obst;               // float32 table (scalar-loaded from the blob, or the LDS copy)
     const double* obst64;       // global float64 rows [K][5] (exact path)
 };
@@ -70,7 +80,9 @@ constexpr float ACT_H_LINE = 0x1.12e0bep-29f, ACT_W_LINE = 0x1.12e0bep-28f, ACT_
 // tick hi[15:0] | attempt << 16 | stream << 24).
 // Streams 0 (step noise) and 4 (sampled actions) are drawn per PAIR of worlds: counter env = world >> 1,
 // the even world uses words 0,1 and the odd world words 2,3 -- a lane that owns two worlds makes one call.
-enum : uint32_t { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3, STREAM_ACT = 4 };
+// Stream 1 holds the placement attempts of a reset: words 0,1 = goal candidate of attempt a, words 2,3 = boat
+// candidate of attempt a.  Stream 3 (attempt 0): heading, wave x, wave y.
+enum : uint32_t { STREAM_STEP = 0, STREAM_PLACE = 1, STREAM_POSE = 3, STREAM_ACT = 4 };
 
 template <bool SCALAR_KEY = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
@@ -78,8 +90,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 product per half round (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32:
+        // integer multiplies issue at a quarter of the VALU rate and are the bulk of this routine
+        const uint64_t p0 = static_cast<uint64_t>(c0) * 0xD2511F53ull;
+        const uint64_t p1 = static_cast<uint64_t>(c2) * 0xCD9E8D57ull;
+        const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+        const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -161,17 +177,35 @@ __device__ __forceinline__ void thrust_to_motion(float vl, float vr, float& h, f
     chord = v * sinc;
 }
 
+// Arguments of an out-of-line device function arrive in VGPRs, so the compiler no longer knows that the
+// table pointer, K, the seed ... are wave-uniform and would read the obstacle rows with per-lane vector
+// loads.  These put them back into SGPRs (v_readfirstlane), which restores scalar loads and SGPR operands.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ uint64_t uni(uint64_t v)
+{
+    return (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
+}
+template <typename P> __device__ __forceinline__ P uni_ptr(P p) { return (P)uni((uint64_t)(uintptr_t)p); }
+
 // ------------------------------------------------------------------------------------ exact path
 // float64, operation order of the reference (aqua.py:159-211).  Contraction is off so that
 // products and sums round where the reference's do.
 struct ExactOut { float x, y, th, reward; uint32_t term; };
 
+// Only the obstacles whose float32 margin is itself inside the band are re-evaluated in float64 (their
+// float32 decision is the reference's decision everywhere else), so the usual cost is zero or one sqrt.
 __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float fgx, float fgy, float fwx,
                                             float fwy, int t_new, double vl, double vr, int K,
-                                            const double* __restrict__ obst64, int time_limit)
+                                            const double* __restrict__ obst64, ObstPtr obst32, float band2,
+                                            int time_limit)
 {
 #pragma clang fp contract(off)
     constexpr double PI_D = 3.141592653589793;
+    K = uni(K); band2 = uni(band2); time_limit = uni(time_limit);
+    obst32 = uni_ptr(obst32);
+    obst64 = (const double*)uni((uint64_t)(uintptr_t)obst64);
     const double px = fx, py = fy, th = fth, gx = fgx, gy = fgy;
     double diff = vr - vl;
     diff = copysign(fmax(fabs(diff), 1e-8), diff);
@@ -189,7 +223,12 @@ __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float
     const double nth = (off - (floor(off / width) * width)) + (-PI_D);
 
     bool hit = (nx - 2.5 < 0.0) || (ny - 2.5 < 0.0) || (nx + 2.5 > 100.0) || (ny + 2.5 > 100.0);
+    const float xs = static_cast<float>(nx), ys = static_cast<float>(ny);
     for (int k = 0; k < K; ++k) {
+        const float qx = fmaxf(fabsf(xs - obst32[k].cx) - obst32[k].hx, 0.0f);
+        const float qy = fmaxf(fabsf(ys - obst32[k].cy) - obst32[k].hy, 0.0f);
+        const float m32 = fmaf(qx, qx, fmaf(qy, qy, -obst32[k].r2));
+        if (fabsf(m32) >= band2) { hit = hit || (m32 < 0.0f); continue; }
         const double* o = obst64 + 5 * k;
         double dist;
         if (o[2] == 0.0) {
@@ -223,12 +262,13 @@ __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float
 // Advances one world in float32.  Returns true when a margin falls inside the knife-edge band
 // (the caller then overrides pose/reward/term with exact_step()).
 //
-// Collision is decided from ONE running minimum of signed margins: the border margin
-// min(x, y) - 2.5, 97.5 - max(x, y) (aqua.py:424-427) and, per obstacle, m = (d^2 - R^2) / (2R) with d the
-// distance from the boat centre to the obstacle's box (aqua.py:373-390, 429-439).  m has exactly the sign
-// of d - R and |m| >= |d - R| / 2, so outside the band the sign of the minimum IS the reference's
-// OR-of-tests, and the strict/non-strict difference of the reference's comparisons only matters at
-// margin == 0, which is inside the band by construction.  ~10 VALU operations per obstacle, no compares.
+// Collision is decided from two signed margins: the border margin min(x, y) - 2.5, 97.5 - max(x, y)
+// (aqua.py:424-427) and the minimum over obstacles of d^2 - R^2 with d the distance from the boat centre
+// to the obstacle's box (aqua.py:373-390, 429-439): 5 VALU operations per circle, 9 per rectangle, no
+// compares.  d^2 - R^2 has exactly the sign of d - R, so outside the bands the sign of the minimum IS the
+// reference's OR-of-tests; |d^2 - R^2| < band2 = 2.5 R_max BAND covers |d - R| < BAND for every R <= R_max,
+// and the strict/non-strict difference of the reference's comparisons only matters at margin == 0,
+// which is inside the band by construction.
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
                                           const StepConst& k, float& reward, uint32_t& term)
 {
@@ -243,13 +283,18 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float wyn = __builtin_amdgcn_fmed3f(fmaf(u1, k.sigma, e.wy), -k.W, k.W);
     const int tn = e.t + 1;                                // aqua.py:141
 
-    float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
+    const float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
+    float mo = 3.0e38f;                                    // min over obstacles of d^2 - R^2
 #pragma unroll 2
-    for (int j = 0; j < k.K; ++j) {
+    for (int j = 0; j < k.Kc; ++j) {                       // circles: distance to the centre
+        const float dx = xn - k.obst[j].cx, dy = yn - k.obst[j].cy;
+        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
+    }
+#pragma unroll 2
+    for (int j = k.Kc; j < k.K; ++j) {                     // rectangles: distance to the box
         const float dx = fmaxf(fabsf(xn - k.obst[j].cx) - k.obst[j].hx, 0.0f);
         const float dy = fmaxf(fabsf(yn - k.obst[j].cy) - k.obst[j].hy, 0.0f);
-        const float d2 = fmaf(dx, dx, dy * dy);
-        mc = fminf(mc, fmaf(d2, k.obst[j].a, k.obst[j].b));
+        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
     }
     // goal distance and shaped reward (aqua.py:89-90, 392-402, 421-422).  prev - cur is formed
     // from the displacement, (|a|^2 - |b|^2) / (|a| + |b|), not as a difference of two norms.
@@ -262,8 +307,8 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float num = fmaf(ddx, ex + fx, ddy * (ey + fy));
     const float shaped = dsum > 0.0f ? 0.7f * (num * __builtin_amdgcn_rcpf(dsum)) : 0.0f;
 
-    const bool knife = fminf(fabsf(mc), fabsf(mg)) < BAND;
-    term = mc < 0.0f ? 1u : (tn > k.time_limit ? 2u : (mg <= 0.0f ? 3u : 0u));   // aqua.py:200-211
+    const bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
+    term = (fminf(mc, mo) < 0.0f) ? 1u : (tn > k.time_limit ? 2u : (mg <= 0.0f ? 3u : 0u));   // aqua.py:200-211
     reward = term == 0u ? shaped : (term == 3u ? 10.0f : -10.0f);
     e.x = xn; e.y = yn; e.th = thn; e.wx = wxn; e.wy = wyn; e.t = tn;
     return knife;
@@ -293,37 +338,39 @@ __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t
 #pragma clang fp contract(off)
     EnvState e;
     constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    K = uni(K); t = uni_ptr(t); seed = uni(seed); tick = uni(tick);
+    waves = uni(waves); random_boat = uni(random_boat); random_goal = uni(random_goal);
     uint32_t r[4];
     float gx = 25.0f, gy = 80.0f;                          // aqua.py:107
     if (random_goal) {
         for (uint32_t a = 0; a < RESET_TRIES; ++a) {       // aqua.py:103-105
-            draw(seed, env, tick, STREAM_GOAL, a, r);
+            draw(seed, env, tick, STREAM_PLACE, a, r);
             const float cx = fmaf(95.0f, u_01(r[0]), 2.5f);
             const float cy = fmaf(95.0f, u_01(r[1]), 2.5f);
             if (!reset_hit(K, t, cx, cy)) { gx = cx; gy = cy; break; }
         }
     }
+    draw(seed, env, tick, STREAM_POSE, 0, r);              // heading (aqua.py:111) and wave (aqua.py:124)
+    const float W = 0.05f * static_cast<float>(waves);
+    const float heading = fmaf(TWO_PI_F, u_01(r[0]), -PI_F);
+    e.wx = W * u_pm1(r[1]);
+    e.wy = W * u_pm1(r[2]);
     float bx = 85.0f, by = 45.0f, bt = 0.0f;               // aqua.py:117
     if (random_boat) {
         for (uint32_t a = 0; a < RESET_TRIES; ++a) {       // aqua.py:111-115
-            draw(seed, env, tick, STREAM_BOAT, a, r);
-            const float cx = fmaf(95.0f, u_01(r[0]), 2.5f);
-            const float cy = fmaf(95.0f, u_01(r[1]), 2.5f);
-            const float ct = fmaf(TWO_PI_F, u_01(r[2]), -PI_F);
+            draw(seed, env, tick, STREAM_PLACE, a, r);
+            const float cx = fmaf(95.0f, u_01(r[2]), 2.5f);
+            const float cy = fmaf(95.0f, u_01(r[3]), 2.5f);
             const float ex = gx - cx, ey = gy - cy;
             const float ey2 = ey * ey;
             const float g2 = fmaf(ex, ex, ey2);
             if (g2 <= 25.0f) continue;
             if (reset_hit(K, t, cx, cy)) continue;
-            bx = cx; by = cy; bt = ct;
+            bx = cx; by = cy; bt = heading;
             break;
         }
     }
-    draw(seed, env, tick, STREAM_WAVE, 0, r);              // aqua.py:124
-    const float W = 0.05f * static_cast<float>(waves);
     e.x = bx; e.y = by; e.th = bt; e.gx = gx; e.gy = gy;
-    e.wx = W * u_pm1(r[0]);
-    e.wy = W * u_pm1(r[1]);
     e.t = 0;                                               // aqua.py:125
     return e;
 }
@@ -331,7 +378,7 @@ __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t
 // The same specification with the attempts of ONE world spread over a group of G adjacent lanes:
 // lane `sub` of the group evaluates attempts sub, sub + G, ... and the group keeps the lowest accepted
 // attempt (ballot + find-first), which is exactly the attempt the serial loop above stops at.  The
-// three Philox chains (goal, boat, wave) of the first round are independent and interleave.  Must be
+// two Philox chains (placement attempt, heading + wave) of the first round are independent and interleave.  Must be
 // called by all 64 lanes of a wavefront together; `active` says whether this lane's group has a world.
 // Every lane of a group returns the group's result.
 template <int G>
@@ -341,53 +388,83 @@ __device__ __noinline__ EnvState reset_env_group(bool active, uint64_t seed, uin
 #pragma clang fp contract(off)
     static_assert(G >= 2 && G <= 64 && (G & (G - 1)) == 0, "group size");
     constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    K = uni(K); t = uni_ptr(t); seed = uni(seed); tick = uni(tick);
+    waves = uni(waves); random_boat = uni(random_boat); random_goal = uni(random_goal);
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int sub = lane & (G - 1), gbase = lane & ~(G - 1);
     const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    uint32_t rg[4], rb[4], rw[4];
-    draw(seed, env, tick, STREAM_GOAL, static_cast<uint32_t>(sub), rg);
-    draw(seed, env, tick, STREAM_BOAT, static_cast<uint32_t>(sub), rb);
-    draw(seed, env, tick, STREAM_WAVE, 0, rw);
-
-    float gx = 25.0f, gy = 80.0f;
-    if (random_goal) {
-        bool found = !active;
-        for (uint32_t base = 0; base < RESET_TRIES; base += G) {
-            if (base != 0) draw(seed, env, tick, STREAM_GOAL, base + sub, rg);
-            const float cx = fmaf(95.0f, u_01(rg[0]), 2.5f);
-            const float cy = fmaf(95.0f, u_01(rg[1]), 2.5f);
-            const bool ok = !found && !reset_hit(K, t, cx, cy);
-            const uint64_t mine = (__ballot(ok) >> gbase) & gmask;
-            const int src = mine ? gbase + __builtin_ctzll(mine) : lane;
-            const float sx = __shfl(cx, src), sy = __shfl(cy, src);
-            if (!found && mine) { gx = sx; gy = sy; found = true; }
-            if (!__any(!found)) break;
-        }
-    }
-    float bx = 85.0f, by = 45.0f, bt = 0.0f;
-    if (random_boat) {
-        bool found = !active;
-        for (uint32_t base = 0; base < RESET_TRIES; base += G) {
-            if (base != 0) draw(seed, env, tick, STREAM_BOAT, base + sub, rb);
-            const float cx = fmaf(95.0f, u_01(rb[0]), 2.5f);
-            const float cy = fmaf(95.0f, u_01(rb[1]), 2.5f);
-            const float ct = fmaf(TWO_PI_F, u_01(rb[2]), -PI_F);
-            const float ex = gx - cx, ey = gy - cy;
-            const float ey2 = ey * ey;
-            const float g2 = fmaf(ex, ex, ey2);
-            const bool ok = !found && !(g2 <= 25.0f) && !reset_hit(K, t, cx, cy);
-            const uint64_t mine = (__ballot(ok) >> gbase) & gmask;
-            const int src = mine ? gbase + __builtin_ctzll(mine) : lane;
-            const float sx = __shfl(cx, src), sy = __shfl(cy, src), st = __shfl(ct, src);
-            if (!found && mine) { bx = sx; by = sy; bt = st; found = true; }
-            if (!__any(!found)) break;
-        }
-    }
+    uint32_t rp[4], rw[4];
+    draw(seed, env, tick, STREAM_PLACE, static_cast<uint32_t>(sub), rp);   // attempt `sub`: goal AND boat candidates
+    draw(seed, env, tick, STREAM_POSE, 0, rw);
     const float W = 0.05f * static_cast<float>(waves);
+    const float heading = fmaf(TWO_PI_F, u_01(rw[0]), -PI_F);
+
+    float gx = 25.0f, gy = 80.0f, bx = 85.0f, by = 45.0f, bt = 0.0f;
+    bool goal_found = !active || !random_goal;
+    bool boat_done = !active || !random_boat;
+    bool serial = false;                 // this group must scan the boat attempts serially from 0 (rare, see below)
+    for (uint32_t base = 0; base < RESET_TRIES; base += G) {
+        if (base != 0) draw(seed, env, tick, STREAM_PLACE, base + sub, rp);
+        const float cgx = fmaf(95.0f, u_01(rp[0]), 2.5f), cgy = fmaf(95.0f, u_01(rp[1]), 2.5f);
+        const float cbx = fmaf(95.0f, u_01(rp[2]), 2.5f), cby = fmaf(95.0f, u_01(rp[3]), 2.5f);
+        // one pass over the obstacle table tests both candidates of this attempt
+        bool hit_g = false, hit_b = false;
+#pragma unroll 2
+        for (int j = 0; j < K; ++j) {
+            const float cx = t[j].cx, cy = t[j].cy, hx = t[j].hx, hy = t[j].hy, r2 = t[j].r2;
+            const float gax = fabsf(cgx - cx), gay = fabsf(cgy - cy);
+            const float gdx = fmaxf(gax - hx, 0.0f), gdy = fmaxf(gay - hy, 0.0f);
+            const float gdy2 = gdy * gdy;
+            hit_g |= fmaf(gdx, gdx, gdy2) <= r2;
+            const float bax = fabsf(cbx - cx), bay = fabsf(cby - cy);
+            const float bdx = fmaxf(bax - hx, 0.0f), bdy = fmaxf(bay - hy, 0.0f);
+            const float bdy2 = bdy * bdy;
+            hit_b |= fmaf(bdx, bdx, bdy2) <= r2;
+        }
+        // goal: lowest accepted attempt of the group (aqua.py:103-105)
+        const uint64_t gm = (__ballot(!goal_found && !hit_g) >> gbase) & gmask;
+        const int gsrc = gm ? gbase + __builtin_ctzll(gm) : lane;
+        const float sgx = __shfl(cgx, gsrc), sgy = __shfl(cgy, gsrc);
+        if (!goal_found && gm) {
+            gx = sgx; gy = sgy; goal_found = true;
+            // the boat attempts are scanned from 0 with the FINAL goal (aqua.py:111-115): a goal that only
+            // turns up in a later round (all G attempts of a round rejected, ~(1 - p)^G) invalidates the
+            // boat candidates of the earlier rounds -> serial scan below
+            if (base != 0 && !boat_done) serial = true;
+        }
+        const float ex = gx - cbx, ey = gy - cby;
+        const float ey2 = ey * ey;
+        const float g2 = fmaf(ex, ex, ey2);
+        const bool boat_ok = goal_found && !boat_done && !serial && !(g2 <= 25.0f) && !hit_b;
+        const uint64_t bm = (__ballot(boat_ok) >> gbase) & gmask;
+        const int bsrc = bm ? gbase + __builtin_ctzll(bm) : lane;
+        const float sbx = __shfl(cbx, bsrc), sby = __shfl(cby, bsrc);
+        if (goal_found && !boat_done && !serial && bm) { bx = sbx; by = sby; bt = heading; boat_done = true; }
+        if (!__any((!goal_found || !boat_done) && !serial)) break;
+    }
+    // goal attempts exhausted: the goal stays at its fixed default (aqua.py:107) and the boat is still scanned
+    if (active && random_boat && !boat_done && !goal_found) serial = true;
+    if (__any(serial)) {
+        if (serial && sub == 0) {
+            uint32_t rr[4];
+            for (uint32_t a = 0; a < RESET_TRIES; ++a) {
+                draw(seed, env, tick, STREAM_PLACE, a, rr);
+                const float cx = fmaf(95.0f, u_01(rr[2]), 2.5f), cy = fmaf(95.0f, u_01(rr[3]), 2.5f);
+                const float fx = gx - cx, fy = gy - cy;
+                const float fy2 = fy * fy;
+                if (fmaf(fx, fx, fy2) <= 25.0f) continue;
+                if (reset_hit(K, t, cx, cy)) continue;
+                bx = cx; by = cy; bt = heading;
+                break;
+            }
+        }
+        const float rbx = __shfl(bx, gbase), rby = __shfl(by, gbase), rbt = __shfl(bt, gbase);
+        if (serial) { bx = rbx; by = rby; bt = rbt; }
+    }
     EnvState e;
     e.x = bx; e.y = by; e.th = bt; e.gx = gx; e.gy = gy;
-    e.wx = W * u_pm1(rw[0]);
-    e.wy = W * u_pm1(rw[1]);
+    e.wx = W * u_pm1(rw[1]);
+    e.wy = W * u_pm1(rw[2]);
     e.t = 0;
     return e;
 }

@@ -128,7 +128,7 @@ __device__ __forceinline__ uint64_t spread_bits(uint64_t x)
 #define AQUA_OBST_DECL __shared__ ObstF s_obst[MAX_OBST];
 __device__ __forceinline__ ObstPtr stage_obstacles(ObstF* s_obst, const void* blob, int K)
 {
-    const float4* src = reinterpret_cast<const float4*>(blob);
+    const float4* src = reinterpret_cast<const float4*>(static_cast<const char*>(blob) + sizeof(ObstHeader));
     float4* dst = reinterpret_cast<float4*>(s_obst);
     for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
@@ -138,7 +138,8 @@ __device__ __forceinline__ ObstPtr stage_obstacles(ObstF* s_obst, const void* bl
 #define AQUA_OBST_DECL ObstF* s_obst = nullptr;
 __device__ __forceinline__ ObstPtr stage_obstacles(ObstF*, const void* blob, int)
 {
-    return (ObstPtr)(uintptr_t)blob;     // rows are read with scalar loads from the constant address space
+    // rows are read with scalar loads from the constant address space (they follow the 32-byte header)
+    return (ObstPtr)(uintptr_t)(static_cast<const char*>(blob) + sizeof(ObstHeader));
 }
 #endif
 
@@ -147,7 +148,15 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K;
     k.obst = obst;
-    k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstF) * a.K);
+    k.Kc = 0; k.band2 = 0.0f;
+    if (a.K > 0) {                       // header fields: uniform scalar loads
+        const ObstHeader __attribute__((address_space(4)))* h =
+            (const ObstHeader __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
+        k.Kc = h->n_circles;
+        k.band2 = h->band2;
+    }
+    k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstHeader) +
+                                               sizeof(ObstF) * a.K);
     return k;
 }
 
@@ -202,6 +211,26 @@ __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u
 // one barrier, groups of RESET_GROUP lanes re-seed them densely (reset_env_group) and write the fresh
 // state straight to HBM; the owning lane then skips its state store for that world.  One workgroup
 // per tile (no grid-stride loop: nothing loop-invariant to hoist, which keeps the SGPR file unspilled).
+// Diagnostic build only (-DAQUA_STAMPS=1, tools/stamps.py): s_memtime stamps per wavefront at phase
+// boundaries, written to a buffer no product code reads.  Never defined in the shipped library.
+#ifndef AQUA_STAMPS
+#define AQUA_STAMPS 0
+#endif
+#if AQUA_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define AQUA_STAMP(slot)                                                                              \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (g_stamps != nullptr && (threadIdx.x & 63) == 0)                                           \
+            g_stamps[(static_cast<size_t>(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define AQUA_STAMP(slot) do { } while (0)
+#endif
+
 struct TileShared {
     uint32_t count;
     uint16_t list[TILE_WORLDS];
@@ -226,6 +255,35 @@ __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_
             w0[2 * p] = r[0]; w1[2 * p] = r[1];
             w0[2 * p + 1] = r[2]; w1[2 * p + 1] = r[3];
         }
+    }
+}
+
+// reward / term / packed done bits of one wavefront's worlds
+template <int VEC>
+__device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, bool full,
+                                              const float (&rew)[VEC], const uint8_t (&code)[VEC], uint32_t done_mask)
+{
+    const int lane = threadIdx.x & 63;
+    if (full) {
+        store_row<VEC, true>(a.reward + tile, off, rem, rew);
+        store_row<VEC, true>(a.term + tile, off, rem, code);
+    } else {
+        store_row<VEC, false>(a.reward + tile, off, rem, rew);
+        store_row<VEC, false>(a.term + tile, off, rem, code);
+    }
+    if (a.done_bits != nullptr) {
+        uint64_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint64_t b = __ballot((done_mask >> j) & 1u);
+#pragma unroll
+            for (int wq = 0; wq < VEC; ++wq) {
+                const uint64_t piece = spread_bits<VEC>(b >> (wq * (64 / VEC))) << j;
+                if (lane == wq) mine |= piece;
+            }
+        }
+        const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u) * VEC) / 64 + lane;
+        if (lane < VEC && word < ((a.N + 63) >> 6)) a.done_bits[word] = mine;
     }
 }
 
@@ -288,6 +346,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { aidx[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; u0[j] = 0.0f; u1[j] = 0.0f; }
     const bool full = rem >= TILE_WORLDS;                // uniform: a whole tile carries no per-lane guards
+    AQUA_STAMP(0);
     if (full) load_inputs<VEC, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
     else load_inputs<VEC, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
 
@@ -308,6 +367,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         }
     }
 
+    AQUA_STAMP(1);          // Philox done (loads may still be in flight)
     float rew[VEC];
     uint8_t code[VEC];
     Motion mo[VEC];
@@ -323,7 +383,9 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         code[j] = static_cast<uint8_t>(c);
         x[j] = e.x; y[j] = e.y; th[j] = e.th; wx[j] = e.wx; wy[j] = e.wy; t[j] = e.t;
     }
-    // knife-edge worlds: redo pose, reward and termination in float64 from the inputs still in memory
+    AQUA_STAMP(2);          // fast path done
+    // knife-edge worlds: redo pose, reward and termination in float64 (reference operation order) from the
+    // inputs still in memory
     if (__any(knife_mask != 0)) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -332,40 +394,21 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
                 double vl, vr;
                 exact_thrusts<AK>(mo[j], vl, vr);
                 const ExactOut o = exact_step(row0[0 * ld + i], row0[1 * ld + i], row0[2 * ld + i], gx[j], gy[j],
-                                              row0[5 * ld + i], row0[6 * ld + i], t[j], vl, vr, k.K, k.obst64,
-                                              k.time_limit);
+                                              row0[5 * ld + i], row0[6 * ld + i], t[j], vl, vr, k.K, k.obst64, k.obst,
+                                              k.band2, k.time_limit);
                 x[j] = o.x; y[j] = o.y; th[j] = o.th; rew[j] = o.reward; code[j] = static_cast<uint8_t>(o.term);
             }
         }
     }
+    AQUA_STAMP(3);          // exact path (if any) done
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
         done_mask |= (code[j] != 0 && static_cast<int64_t>(off) + j < rem) ? (1u << j) : 0u;
+    store_outputs<VEC>(a, tile, off, rem, full, rew, code, done_mask);
 
-    // outputs of the step that just happened
-    if (full) {
-        store_row<VEC, true>(a.reward + tile, off, rem, rew);
-        store_row<VEC, true>(a.term + tile, off, rem, code);
-    } else {
-        store_row<VEC, false>(a.reward + tile, off, rem, rew);
-        store_row<VEC, false>(a.term + tile, off, rem, code);
-    }
-    if (a.done_bits != nullptr) {
-        uint64_t mine = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const uint64_t b = __ballot((done_mask >> j) & 1u);
-#pragma unroll
-            for (int wq = 0; wq < VEC; ++wq) {
-                const uint64_t piece = spread_bits<VEC>(b >> (wq * (64 / VEC))) << j;
-                if (lane == wq) mine |= piece;
-            }
-        }
-        const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u) * VEC) / 64 + lane;
-        if (lane < VEC && word < ((a.N + 63) >> 6)) a.done_bits[word] = mine;
-    }
-
-    uint32_t skip_mask = 0;        // worlds whose state is written by a re-seeding group instead
+    // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
+    uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
+    constexpr uint32_t own_reset_mask = 0;
     if (a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
@@ -374,7 +417,9 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             if (done_mask & (1u << j)) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off + j);
         }
         skip_mask = done_mask;
+        AQUA_STAMP(4);      // outputs stored, list appended
         __syncthreads();
+        AQUA_STAMP(5);      // barrier passed
         const uint32_t n_done = *cnt;
         constexpr uint32_t GROUPS = BLOCK / RESET_GROUP;
         const uint32_t wave_first_group = (threadIdx.x & ~63u) / RESET_GROUP;
@@ -392,7 +437,9 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             }
         }
     }
-    if (skip_mask == 0 && full) {
+    AQUA_STAMP(6);          // group re-seeding done
+
+    if (skip_mask == 0 && own_reset_mask == 0 && full) {
         store_row<VEC, true>(row0 + 0 * ld, off, rem, x);
         store_row<VEC, true>(row0 + 1 * ld, off, rem, y);
         store_row<VEC, true>(row0 + 2 * ld, off, rem, th);
@@ -410,6 +457,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             }
         }
     }
+    AQUA_STAMP(7);          // state stores issued
 }
 
 template <int VEC, int AK>
@@ -466,7 +514,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
                     double dl, dr;
                     exact_thrusts<AK>(m, dl, dr);
                     const ExactOut o = exact_step(before.x, before.y, before.th, before.gx, before.gy, before.wx,
-                                                  before.wy, e.t, dl, dr, k.K, k.obst64, k.time_limit);
+                                                  before.wy, e.t, dl, dr, k.K, k.obst64, k.obst, k.band2, k.time_limit);
                     e.x = o.x; e.y = o.y; e.th = o.th; rew = o.reward; code = o.term;
                 }
             }
@@ -642,7 +690,7 @@ const char* aqua_last_error(void) { return g_err; }
 size_t aqua_obstacle_blob_bytes(int K)
 {
     if (K <= 0) return 0;
-    return static_cast<size_t>(K) * (sizeof(ObstF) + 5 * sizeof(double));
+    return sizeof(ObstHeader) + static_cast<size_t>(K) * (sizeof(ObstF) + 5 * sizeof(double));
 }
 
 int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_bytes)
@@ -651,22 +699,35 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
     if (K == 0) return 0;
     if (rows == nullptr || blob_host == nullptr) return fail(AQUA_E_INVALID, "rows/blob is NULL");
     if (blob_bytes < aqua_obstacle_blob_bytes(K)) return fail(AQUA_E_INVALID, "blob too small");
-    ObstF* f = static_cast<ObstF*>(blob_host);
-    double* d = reinterpret_cast<double*>(static_cast<char*>(blob_host) + sizeof(ObstF) * K);
+    ObstHeader* h = static_cast<ObstHeader*>(blob_host);
+    ObstF* f = reinterpret_cast<ObstF*>(static_cast<char*>(blob_host) + sizeof(ObstHeader));
+    double* d = reinterpret_cast<double*>(static_cast<char*>(blob_host) + sizeof(ObstHeader) + sizeof(ObstF) * K);
+    std::memset(blob_host, 0, aqua_obstacle_blob_bytes(K));
+    int n_circles = 0;
     for (int k = 0; k < K; ++k) {
         const double* o = rows + 5 * k;
         if (!(o[2] == 0.0 || o[2] == 1.0)) return fail(AQUA_E_INVALID, "obstacle %d: kind must be 0 or 1", k);
+        n_circles += o[2] == 0.0;
+    }
+    double r_max = 0.0;
+    int ic = 0, ir = n_circles;                          // circles first, rectangles after (original order kept)
+    for (int k = 0; k < K; ++k) {
+        const double* o = rows + 5 * k;
         double hx = 0, hy = 0, R = 2.5;                 // boat radius (aqua.py:75)
         if (o[2] == 0.0) R += o[3]; else { hx = o[3] / 2; hy = o[4] / 2; }
-        if (!(R > 0.0) || hx < 0.0 || hy < 0.0) return fail(AQUA_E_INVALID, "obstacle %d: negative size", k);
-        f[k].cx = static_cast<float>(o[0]); f[k].cy = static_cast<float>(o[1]);
-        f[k].hx = static_cast<float>(hx); f[k].hy = static_cast<float>(hy);
-        f[k].a = static_cast<float>(1.0 / (2.0 * R));
-        f[k].b = static_cast<float>(-R / 2.0);
-        f[k].r2 = static_cast<float>(R * R);
-        f[k].pad = 0.0f;
-        for (int j = 0; j < 5; ++j) d[5 * k + j] = o[j];
+        if (!(R > 0.0) || hx < 0.0 || hy < 0.0 || (o[2] == 0.0 && o[3] < 0.0))
+            return fail(AQUA_E_INVALID, "obstacle %d: negative size", k);
+        const int slot = o[2] == 0.0 ? ic++ : ir++;
+        f[slot].cx = static_cast<float>(o[0]); f[slot].cy = static_cast<float>(o[1]);
+        f[slot].hx = static_cast<float>(hx); f[slot].hy = static_cast<float>(hy);
+        f[slot].r2 = static_cast<float>(R * R);
+        if (R > r_max) r_max = R;
+        for (int j = 0; j < 5; ++j) d[5 * slot + j] = o[j];
     }
+    h->n_obstacles = K;
+    h->n_circles = n_circles;
+    h->r_max = static_cast<float>(r_max);
+    h->band2 = static_cast<float>(2.5 * (r_max + static_cast<double>(BAND)) * static_cast<double>(BAND));
     return 0;
 }
 
@@ -683,6 +744,14 @@ void aqua_discrete_constants(float out[9])
                         ACT_C_TURN, ACT_C_TURN, ACT_C_LINE};
     for (int j = 0; j < 9; ++j) out[j] = v[j];
 }
+
+#if AQUA_STAMPS
+int aqua_debug_set_stamps(unsigned long long* dev_ptr)
+{
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_ptr, sizeof(dev_ptr));
+    return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyToSymbol(g_stamps)");
+}
+#endif
 
 int aqua_set_vector_width(int width)
 {

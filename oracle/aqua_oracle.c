@@ -58,7 +58,9 @@ void aqua_oracle_philox(uint32_t k0, uint32_t k1, const uint32_t ctr[4], uint32_
 }
 
 /* stream ids of this build's RNG specification (DESIGN.md "RNG") */
-enum { STREAM_STEP = 0, STREAM_GOAL = 1, STREAM_BOAT = 2, STREAM_WAVE = 3, STREAM_ACT = 4 };
+/* 0: step noise (per pair of worlds); 1: placement attempts of reset (words 0,1 = goal candidate of attempt a,
+ * words 2,3 = boat candidate of attempt a); 3: heading + wave of reset; 4: sampled actions (per pair) */
+enum { STREAM_STEP = 0, STREAM_PLACE = 1, STREAM_POSE = 3, STREAM_ACT = 4 };
 
 static inline void aqua_draw(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, uint32_t attempt,
                              uint32_t out[4])
@@ -310,32 +312,32 @@ void aqua_oracle_reset(int64_t n, int K, const double* obst, int waves, int rand
         float gx = 25.0f, gy = 80.0f;
         if (random_goal) {
             for (uint32_t a = 0; a < RESET_TRIES; ++a) {
-                aqua_draw(seed, env, tick, STREAM_GOAL, a, r);
+                aqua_draw(seed, env, tick, STREAM_PLACE, a, r);
                 float cx = fmaf(95.0f, u01f(r[0]), 2.5f);
                 float cy = fmaf(95.0f, u01f(r[1]), 2.5f);
                 if (!hit_f32(K, t, cx, cy)) { gx = cx; gy = cy; break; }
             }
         }
+        aqua_draw(seed, env, tick, STREAM_POSE, 0, r);          /* heading and wave: independent of acceptance */
+        float W = 0.05f * (float)waves;
+        float heading = fmaf(TWO_PI_F, u01f(r[0]), -PI_F);
+        float wx = W * (float)u_pm1(r[1]);
+        float wy = W * (float)u_pm1(r[2]);
         float bx = 85.0f, by = 45.0f, bt = 0.0f;
         if (random_boat) {
             for (uint32_t a = 0; a < RESET_TRIES; ++a) {
-                aqua_draw(seed, env, tick, STREAM_BOAT, a, r);
-                float cx = fmaf(95.0f, u01f(r[0]), 2.5f);
-                float cy = fmaf(95.0f, u01f(r[1]), 2.5f);
-                float ct = fmaf(TWO_PI_F, u01f(r[2]), -PI_F);
+                aqua_draw(seed, env, tick, STREAM_PLACE, a, r);
+                float cx = fmaf(95.0f, u01f(r[2]), 2.5f);
+                float cy = fmaf(95.0f, u01f(r[3]), 2.5f);
                 float ex = gx - cx, ey = gy - cy;
                 float ey2 = ey * ey;
                 float g2 = fmaf(ex, ex, ey2);
                 if (g2 <= 25.0f) continue;                       /* on the goal: aqua.py:112 */
                 if (hit_f32(K, t, cx, cy)) continue;
-                bx = cx; by = cy; bt = ct;
+                bx = cx; by = cy; bt = heading;
                 break;
             }
         }
-        aqua_draw(seed, env, tick, STREAM_WAVE, 0, r);
-        float W = 0.05f * (float)waves;
-        float wx = W * (float)u_pm1(r[0]);
-        float wy = W * (float)u_pm1(r[1]);
         state[0 * ld + i] = bx; state[1 * ld + i] = by; state[2 * ld + i] = bt;
         state[3 * ld + i] = gx; state[4 * ld + i] = gy;
         state[5 * ld + i] = wx; state[6 * ld + i] = wy;

@@ -1,0 +1,114 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the N > 1 path: range partition + the done-mask
+all-gather.  The worlds themselves are stepped by the CPU oracle here (the HIP kernels need a GPU);
+what is under test is the host logic that bench.py and a multi-GPU user run around the kernels:
+shard_range(), DoneMaskExchange and the shard-invariance of the Philox keying (global world index)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from aquaticgymenv_amd.sharded import DoneMaskExchange, shard_range, unpack_done_words
+
+
+def test_shard_range_partitions_exactly():
+    for total in (1, 63, 64, 65, 1000, 4096, 262144, 2097152, 2097153):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            covered = 0
+            for o, c in spans:                       # non-empty shards tile [0, total) in rank order
+                if c:
+                    assert o == covered
+                    covered += c
+            assert covered == total
+            assert all(o % 64 == 0 for o, _ in spans)
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _pack(done):
+    n = done.shape[0]
+    pad = (-n) % 64
+    bits = np.concatenate([done.astype(np.uint8), np.zeros(pad, dtype=np.uint8)])
+    return np.packbits(bits, bitorder="little").view(np.uint64).astype(np.uint64)
+
+
+def _worker(rank, world, port, total, steps, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.aqua_oracle import COracle
+        from aquaticgymenv_amd import presets
+        orc = COracle()
+        off, cnt = shard_range(total, world, rank)
+        words = (shard_range(total, world, 0)[1] + 63) // 64          # the largest shard: every rank pads to it
+        st = np.zeros((7, cnt), dtype=np.float32)
+        tt = np.zeros(cnt, dtype=np.int32)
+        orc.reset(st, tt, obstacles=presets.BENCH8, seed=11, tick=0, env_offset=off)
+        ex = DoneMaskExchange(steps, words, "cpu")
+        local = torch.zeros((steps, words), dtype=torch.int64)
+        for t in range(steps):
+            _, _, term, _ = orc.rollout_f32(st, tt, 1, obstacles=presets.BENCH8, seed=11, tick0=1 + t, env_offset=off)
+            w = _pack(term != 0)
+            local[t, : w.shape[0]] = torch.from_numpy(w.view(np.int64))
+        slot = ex.gather_async(local)
+        ex.wait(slot)
+        ex.finish()
+        g = ex.gathered[slot].numpy()
+        assert g.shape == (world, steps, words)
+        np.save(os.path.join(tmpdir, "gathered_%d.npy" % rank), g)
+        np.save(os.path.join(tmpdir, "state_%d.npy" % rank), st)
+        # every rank holds the same gathered block
+        t0 = torch.from_numpy(g.copy())
+        dist.broadcast(t0, src=0)
+        assert np.array_equal(t0.numpy(), g)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_rollout_matches_single_process(tmp_path):
+    total, steps, world = 5000, 12, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True)
+    from oracle.aqua_oracle import COracle
+    from aquaticgymenv_amd import presets
+    orc = COracle()
+    st = np.zeros((7, total), dtype=np.float32)
+    tt = np.zeros(total, dtype=np.int32)
+    orc.reset(st, tt, obstacles=presets.BENCH8, seed=11, tick=0)
+    dones = []
+    for t in range(steps):
+        _, _, term, _ = orc.rollout_f32(st, tt, 1, obstacles=presets.BENCH8, seed=11, tick0=1 + t)
+        dones.append((term != 0).astype(np.uint8))
+    g = np.load(tmp_path / "gathered_0.npy")
+    assert np.array_equal(g, np.load(tmp_path / "gathered_1.npy"))
+    spans = [shard_range(total, world, r) for r in range(world)]
+    for t in range(steps):
+        got = np.concatenate([unpack_done_words(g[r, t], spans[r][1]) for r in range(world)])
+        assert np.array_equal(got, dones[t])
+    # shard invariance of the state itself (Philox keyed by the global world index)
+    whole = np.concatenate([np.load(tmp_path / ("state_%d.npy" % r)) for r in range(world)], axis=1)
+    assert np.array_equal(whole, st)
+
+
+def test_exchange_world_size_one_cpu():
+    ex = DoneMaskExchange(3, 4, "cpu")
+    x = torch.arange(12, dtype=torch.int64).reshape(3, 4)
+    slot = ex.gather_async(x)
+    ex.finish()
+    assert torch.equal(ex.gathered[slot][0], x)
+    with pytest.raises(ValueError):
+        ex.gather_async(torch.zeros((2, 4), dtype=torch.int64))

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of library variants on ONE GPU box (each measurement in a fresh process).
+usage: python tools/ab.py [--rounds 3] [--envs N] name1 name2 ...   (name = variant under lib/variants or 'default')"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--envs", type=int, default=262144)
+ap.add_argument("--steps", type=int, default=1000)
+ap.add_argument("--extra", default="")
+ap.add_argument("names", nargs="+")
+args = ap.parse_args()
+
+CHILD = r'''
+import sys, os
+sys.path.insert(0, %r)
+import torch
+from aquaticgymenv_amd import presets
+from aquaticgymenv_amd.batched import BatchedAqua
+n, steps = %d, %d
+env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=True, device="cuda:0")
+env.reset()
+g = torch.Generator(device="cuda").manual_seed(1)
+acts = torch.randint(0, 3, (100, env.ld), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+graph = env.capture_rollout(100, actions=acts, keep_all=False)
+for _ in range(3): graph.launch()
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps // 100): graph.launch()
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) * 1e3 / (steps // 100 * 100))
+print("%%.3f" %% best)
+''' % (ROOT, args.envs, args.steps)
+
+res = {n: [] for n in args.names}
+for r in range(args.rounds):
+    for name in args.names:
+        env = dict(os.environ)
+        if name != "default":
+            env["AQUA_HIP_LIB"] = os.path.join(ROOT, "aquaticgymenv_amd", "lib", "variants", "libaqua_hip_%s.so" % name)
+        else:
+            env.pop("AQUA_HIP_LIB", None)
+        out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+        try:
+            res[name].append(float(out.stdout.strip().splitlines()[-1]))
+        except Exception:
+            print("FAILED", name, out.stderr[-500:])
+for name in args.names:
+    v = res[name]
+    if v:
+        print("%-16s us/step: min %.2f  median %.2f  all %s" % (name, min(v), sorted(v)[len(v) // 2], " ".join("%.2f" % x for x in v)))
