@@ -216,6 +216,9 @@ __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u
 #ifndef AQUA_STAMPS
 #define AQUA_STAMPS 0
 #endif
+#ifndef AQUA_WAVE_RESET
+#define AQUA_WAVE_RESET 0
+#endif
 #if AQUA_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
 #define AQUA_STAMP(slot)                                                                              \
@@ -409,6 +412,35 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
     uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
     constexpr uint32_t own_reset_mask = 0;
+#if AQUA_WAVE_RESET
+    // variant: every wavefront re-seeds its own finished worlds right away (no list, no barrier)
+    if (a.auto_reset) {
+        skip_mask = done_mask;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            uint64_t m = __ballot((done_mask >> j) & 1u);
+            while (m != 0) {
+                int owner = -1;
+#pragma unroll
+                for (int g = 0; g < 64 / RESET_GROUP; ++g) {
+                    const int o = m ? __builtin_ctzll(m) : -1;
+                    if (lane / RESET_GROUP == g) owner = o;
+                    m &= m - 1;
+                }
+                const bool active = owner >= 0;
+                const uint32_t i = ((threadIdx.x & ~63u) + (active ? owner : 0)) * VEC + j;
+                const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
+                                                                tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+                if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                    row0[0 * ld + i] = e.x; row0[1 * ld + i] = e.y; row0[2 * ld + i] = e.th;
+                    row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
+                    row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
+                    trow[i] = e.t;
+                }
+            }
+        }
+    }
+#else
     if (a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
@@ -437,6 +469,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             }
         }
     }
+#endif
     AQUA_STAMP(6);          // group re-seeding done
 
     if (skip_mask == 0 && own_reset_mask == 0 && full) {
