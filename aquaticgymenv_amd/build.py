@@ -62,7 +62,6 @@ if __name__ == "__main__":
     if "--variants" in sys.argv:
         for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("tile512", ["-DAQUA_TILE=512"]),
                             ("tile1024_lds", ["-DAQUA_OBST_LDS=1"]), ("group4", ["-DAQUA_RESET_GROUP=4"]),
-                            ("group16", ["-DAQUA_RESET_GROUP=16"]), ("stamps", ["-DAQUA_STAMPS=1"]), ("wavereset", ["-DAQUA_WAVE_RESET=1"]),
-                            ("wavereset_t256", ["-DAQUA_WAVE_RESET=1", "-DAQUA_TILE=256"])):
+                            ("group16", ["-DAQUA_RESET_GROUP=16"]), ("stamps", ["-DAQUA_STAMPS=1"]), ("noinl", ["-DAQUA_INLINE_RESEED=0"])):
             print(build_variant(name, flags, verbose=True))
     print(build_hip(force="--force" in sys.argv, verbose=True))

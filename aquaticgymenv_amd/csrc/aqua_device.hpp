@@ -190,14 +190,77 @@ __device__ __forceinline__ uint64_t uni(uint64_t v)
 template <typename P> __device__ __forceinline__ P uni_ptr(P p) { return (P)uni((uint64_t)(uintptr_t)p); }
 
 // ------------------------------------------------------------------------------------ exact path
-// float64, operation order of the reference (aqua.py:159-211).  Contraction is off so that
-// products and sums round where the reference's do.
+// float64, operation order of the reference (aqua.py:159-211).  Contraction is off so that products and
+// sums round where the reference's do.  The path is rare (~2e-5 of world-steps) but whatever it costs is
+// added to the launch (some wavefront in a 262 144-world batch takes it in practically every step), so
+// it is written for latency: inputs come from registers, sin/cos are a compact bounded-argument
+// routine instead of the library's generic one, the discrete-action quantities are literals, and only
+// the obstacles whose float32 margin is itself inside the band are re-evaluated in float64.
 struct ExactOut { float x, y, th, reward; uint32_t term; };
 
-// Only the obstacles whose float32 margin is itself inside the band are re-evaluated in float64 (their
-// float32 decision is the reference's decision everywhere else), so the usual cost is zero or one sqrt.
+// sin and cos of |x| <~ 8 in float64, < 1 ulp: three-stage Cody-Waite reduction by pi/2 (the constants and
+// the two kernels are fdlibm's __ieee754_rem_pio2 medium path, __kernel_sin and __kernel_cos).  It returns
+// the same bits as libm for the arguments the reference's special cases hit (sin(fl(pi/2)) == 1,
+// cos(fl(pi/2)) == 6.123233995736766e-17, sin(4e-9) == 4e-9, cos(4e-9) == 1).
+__device__ __forceinline__ void sincos_f64(double x, double& s, double& c)
+{
+#pragma clang fp contract(off)
+    constexpr double INVPIO2 = 6.36619772367581382433e-01;
+    constexpr double P1 = 0x1.921fb54400000p+0, P1T = 0x1.0b4611a626331p-34;
+    constexpr double P2 = 0x1.0b4611a600000p-34, P2T = 0x1.3198a2e037073p-69;
+    constexpr double P3 = 0x1.3198a2e000000p-69, P3T = 0x1.b839a252049c1p-104;
+    const double fn = rint(x * INVPIO2);
+    double r = x - fn * P1, w = fn * P1T, t;
+    t = r; w = fn * P2; r = t - w; w = fn * P2T - ((t - r) - w);
+    t = r; w = fn * P3; r = t - w; w = fn * P3T - ((t - r) - w);
+    const double y0 = r - w, y1 = (r - y0) - w;
+    const double z = y0 * y0;
+    // __kernel_sin(y0, y1)
+    const double v = z * y0;
+    const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+    // __kernel_cos(y0, y1)
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z, wc = 1.0 - hz;
+    const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    const int q = static_cast<int>(fn) & 3;
+    const double s0 = (q & 1) ? kc : ks, c0 = (q & 1) ? ks : kc;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// turn radius, angular step and its cosine/sine (aqua.py:159-170,176).  Discrete actions (aqua.py:33-42):
+// the reference's own float64 values, computed once with its expressions.
+struct ExactMotion { double r, w, cw, sw; };
+
+__device__ __forceinline__ ExactMotion exact_motion_discrete(int idx)
+{
+    ExactMotion m;
+    const bool line = idx == 2;
+    const double sign = idx == 1 ? -1.0 : 1.0;
+    m.r = line ? 0x1.dcd65p+26 : sign * 0x1.7555555555556p+1;                  // 1.25 (vR+vL) / d
+    m.w = line ? 0x1.12e0be826d695p-28 : sign * 0x1.eb851eb851eb8p-4;          // d / 2.5
+    m.cw = line ? 1.0 : 0x1.fc5169dc5b825p-1;
+    m.sw = line ? 0x1.12e0be826d695p-28 : sign * 0x1.ea5758f3ce5cdp-4;
+    return m;
+}
+
+__device__ __forceinline__ ExactMotion exact_motion_continuous(double vl, double vr)
+{
+#pragma clang fp contract(off)
+    ExactMotion m;
+    double diff = vr - vl;
+    diff = copysign(fmax(fabs(diff), 1e-8), diff);
+    m.r = 2.5 / 2 * (vr + vl) / diff;
+    m.w = diff / 2.5;
+    sincos_f64(m.w, m.sw, m.cw);
+    return m;
+}
+
 __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float fgx, float fgy, float fwx,
-                                            float fwy, int t_new, double vl, double vr, int K,
+                                            float fwy, int t_new, ExactMotion mo, int K,
                                             const double* __restrict__ obst64, ObstPtr obst32, float band2,
                                             int time_limit)
 {
@@ -207,27 +270,28 @@ __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float
     obst32 = uni_ptr(obst32);
     obst64 = (const double*)uni((uint64_t)(uintptr_t)obst64);
     const double px = fx, py = fy, th = fth, gx = fgx, gy = fgy;
-    double diff = vr - vl;
-    diff = copysign(fmax(fabs(diff), 1e-8), diff);
-    const double r = 2.5 / 2 * (vr + vl) / diff;
-    const double w = diff / 2.5;
+    const double r = mo.r, w = mo.w, c = mo.cw, s = mo.sw;
     const double angle = PI_D / 2 + th;
-    const double icc_x = px + r * (-sin(angle));
-    const double icc_y = py + r * cos(angle);
-    const double c = cos(w), s = sin(w);
+    double sa, ca;
+    sincos_f64(angle, sa, ca);
+    const double icc_x = px + r * (-sa);
+    const double icc_y = py + r * ca;
     const double qx = px - icc_x, qy = py - icc_y;
     const double nx = (c * qx + (-s) * qy) + icc_x + static_cast<double>(fwx);
     const double ny = (s * qx + c * qy) + icc_y + static_cast<double>(fwy);
+    // aqua.py:128-133: off - floor(off / width) * width - pi.  floor(off / width) is 0, 1 or -1 here; the
+    // comparison form gives the same integer without a float64 division (|off| < 2 * width).
     const double width = PI_D - (-PI_D);
     const double off = (th + w) - (-PI_D);
-    const double nth = (off - (floor(off / width) * width)) + (-PI_D);
+    const double turns = off >= width ? 1.0 : (off < 0.0 ? -1.0 : 0.0);
+    const double nth = (off - (turns * width)) + (-PI_D);
 
     bool hit = (nx - 2.5 < 0.0) || (ny - 2.5 < 0.0) || (nx + 2.5 > 100.0) || (ny + 2.5 > 100.0);
     const float xs = static_cast<float>(nx), ys = static_cast<float>(ny);
     for (int k = 0; k < K; ++k) {
-        const float qx = fmaxf(fabsf(xs - obst32[k].cx) - obst32[k].hx, 0.0f);
-        const float qy = fmaxf(fabsf(ys - obst32[k].cy) - obst32[k].hy, 0.0f);
-        const float m32 = fmaf(qx, qx, fmaf(qy, qy, -obst32[k].r2));
+        const float bx = fmaxf(fabsf(xs - obst32[k].cx) - obst32[k].hx, 0.0f);
+        const float by = fmaxf(fabsf(ys - obst32[k].cy) - obst32[k].hy, 0.0f);
+        const float m32 = fmaf(bx, bx, fmaf(by, by, -obst32[k].r2));
         if (fabsf(m32) >= band2) { hit = hit || (m32 < 0.0f); continue; }
         const double* o = obst64 + 5 * k;
         double dist;
@@ -245,13 +309,15 @@ __device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float
     }
     const double ex = gx - nx, ey = gy - ny;
     const double d_cur = sqrt(ex * ex + ey * ey) - (2.5 + 2.5);
-    const double ox = gx - px, oy = gy - py;
-    const double d_prev = sqrt(ox * ox + oy * oy) - (2.5 + 2.5);
     ExactOut out;
     if (hit) { out.term = 1; out.reward = -10.0f; }
     else if (t_new > time_limit) { out.term = 2; out.reward = -10.0f; }
     else if (d_cur <= 0.0) { out.term = 3; out.reward = 10.0f; }
-    else { out.term = 0; out.reward = static_cast<float>((d_prev - d_cur) * 0.7); }
+    else {
+        const double ox = gx - px, oy = gy - py;
+        const double d_prev = sqrt(ox * ox + oy * oy) - (2.5 + 2.5);
+        out.term = 0; out.reward = static_cast<float>((d_prev - d_cur) * 0.7);
+    }
     out.x = static_cast<float>(nx);
     out.y = static_cast<float>(ny);
     out.th = static_cast<float>(nth);
@@ -381,8 +447,16 @@ __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t
 // two Philox chains (placement attempt, heading + wave) of the first round are independent and interleave.  Must be
 // called by all 64 lanes of a wavefront together; `active` says whether this lane's group has a world.
 // Every lane of a group returns the group's result.
+#ifndef AQUA_INLINE_RESEED
+#define AQUA_INLINE_RESEED 1
+#endif
+#if AQUA_INLINE_RESEED
+#define AQUA_RESEED_ATTR __forceinline__
+#else
+#define AQUA_RESEED_ATTR __noinline__
+#endif
 template <int G>
-__device__ __noinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
+__device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t)
 {
 #pragma clang fp contract(off)

@@ -190,14 +190,14 @@ __device__ __forceinline__ Motion decode_motion(const StepConst& k, int idx, flo
 }
 
 template <int AK>
-__device__ __forceinline__ void exact_thrusts(const Motion& m, double& vl, double& vr)
+__device__ __forceinline__ ExactMotion exact_motion(const Motion& m)
 {
     if constexpr (AK == AQUA_ACT_F32X2 || AK == AQUA_ACT_SAMPLE_C) {
-        vl = fmin(fmax(static_cast<double>(m.vl), 0.2), 0.5);
-        vr = fmin(fmax(static_cast<double>(m.vr), 0.2), 0.5);
+        const double vl = fmin(fmax(static_cast<double>(m.vl), 0.2), 0.5);      // aqua.py:145-150
+        const double vr = fmin(fmax(static_cast<double>(m.vr), 0.2), 0.5);
+        return exact_motion_continuous(vl, vr);
     } else {
-        vl = m.idx == 0 ? 0.2 : 0.5;     // aqua.py:36-41
-        vr = m.idx == 1 ? 0.2 : 0.5;
+        return exact_motion_discrete(m.idx);                                     // aqua.py:33-42
     }
 }
 
@@ -219,6 +219,7 @@ __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u
 #ifndef AQUA_WAVE_RESET
 #define AQUA_WAVE_RESET 0
 #endif
+
 #if AQUA_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
 #define AQUA_STAMP(slot)                                                                              \
@@ -230,8 +231,19 @@ __device__ unsigned long long* g_stamps = nullptr;
         if (g_stamps != nullptr && (threadIdx.x & 63) == 0)                                           \
             g_stamps[(static_cast<size_t>(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (slot)] = t_; \
     } while (0)
+// wall-clock stamp (s_memrealtime, 100 MHz, common to all XCDs) into slots 8.. of the same record
+#define AQUA_RTSTAMP(slot)                                                                            \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (g_stamps != nullptr && (threadIdx.x & 63) == 0)                                           \
+            g_stamps[(static_cast<size_t>(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (slot)] = t_; \
+    } while (0)
 #else
 #define AQUA_STAMP(slot) do { } while (0)
+#define AQUA_RTSTAMP(slot) do { } while (0)
 #endif
 
 struct TileShared {
@@ -349,7 +361,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { aidx[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; u0[j] = 0.0f; u1[j] = 0.0f; }
     const bool full = rem >= TILE_WORLDS;                // uniform: a whole tile carries no per-lane guards
-    AQUA_STAMP(0);
+    AQUA_RTSTAMP(0);
     if (full) load_inputs<VEC, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
     else load_inputs<VEC, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
 
@@ -374,9 +386,11 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     float rew[VEC];
     uint8_t code[VEC];
     Motion mo[VEC];
+    float x0[VEC], y0[VEC], th0[VEC], wx0[VEC], wy0[VEC];      // step inputs, kept for the exact path
     uint32_t knife_mask = 0, done_mask = 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
+        x0[j] = x[j]; y0[j] = y[j]; th0[j] = th[j]; wx0[j] = wx[j]; wy0[j] = wy[j];
         EnvState e{x[j], y[j], th[j], gx[j], gy[j], wx[j], wy[j], t[j]};
         mo[j] = decode_motion<AK>(k, aidx[j], avl[j], avr[j]);
         uint32_t c;
@@ -387,18 +401,13 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         x[j] = e.x; y[j] = e.y; th[j] = e.th; wx[j] = e.wx; wy[j] = e.wy; t[j] = e.t;
     }
     AQUA_STAMP(2);          // fast path done
-    // knife-edge worlds: redo pose, reward and termination in float64 (reference operation order) from the
-    // inputs still in memory
+    // knife-edge worlds: redo pose, reward and termination in float64 (reference operation order)
     if (__any(knife_mask != 0)) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (knife_mask & (1u << j)) {
-                const uint32_t i = off + j;
-                double vl, vr;
-                exact_thrusts<AK>(mo[j], vl, vr);
-                const ExactOut o = exact_step(row0[0 * ld + i], row0[1 * ld + i], row0[2 * ld + i], gx[j], gy[j],
-                                              row0[5 * ld + i], row0[6 * ld + i], t[j], vl, vr, k.K, k.obst64, k.obst,
-                                              k.band2, k.time_limit);
+                const ExactOut o = exact_step(x0[j], y0[j], th0[j], gx[j], gy[j], wx0[j], wy0[j], t[j],
+                                              exact_motion<AK>(mo[j]), k.K, k.obst64, k.obst, k.band2, k.time_limit);
                 x[j] = o.x; y[j] = o.y; th[j] = o.th; rew[j] = o.reward; code[j] = static_cast<uint8_t>(o.term);
             }
         }
@@ -490,7 +499,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             }
         }
     }
-    AQUA_STAMP(7);          // state stores issued
+    AQUA_RTSTAMP(7);        // state stores issued (wall clock)
 }
 
 template <int VEC, int AK>
@@ -544,10 +553,9 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
             const bool knife = fast_step(e, m.h, m.w, m.chord, u0, u1, k, rew, code);
             if (__any(knife)) {
                 if (knife) {
-                    double dl, dr;
-                    exact_thrusts<AK>(m, dl, dr);
                     const ExactOut o = exact_step(before.x, before.y, before.th, before.gx, before.gy, before.wx,
-                                                  before.wy, e.t, dl, dr, k.K, k.obst64, k.obst, k.band2, k.time_limit);
+                                                  before.wy, e.t, exact_motion<AK>(m), k.K, k.obst64, k.obst, k.band2,
+                                                  k.time_limit);
                     e.x = o.x; e.y = o.y; e.th = o.th; rew = o.reward; code = o.term;
                 }
             }

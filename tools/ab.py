@@ -19,8 +19,9 @@ CHILD = r'''
 import sys, os
 sys.path.insert(0, %r)
 import torch
-from aquaticgymenv_amd import presets
+from aquaticgymenv_amd import presets, _capi
 from aquaticgymenv_amd.batched import BatchedAqua
+_capi.lib.aqua_set_vector_width(int(os.environ.get("AQUA_VEC", "0")))
 n, steps = %d, %d
 env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=True, device="cuda:0")
 env.reset()
@@ -43,13 +44,15 @@ res = {n: [] for n in args.names}
 for r in range(args.rounds):
     for name in args.names:
         env = dict(os.environ)
+        name, _, vec = name.partition(":")
+        env["AQUA_VEC"] = vec or "0"
         if name != "default":
             env["AQUA_HIP_LIB"] = os.path.join(ROOT, "aquaticgymenv_amd", "lib", "variants", "libaqua_hip_%s.so" % name)
         else:
             env.pop("AQUA_HIP_LIB", None)
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
         try:
-            res[name].append(float(out.stdout.strip().splitlines()[-1]))
+            res[name + (":" + vec if vec else "")].append(float(out.stdout.strip().splitlines()[-1]))
         except Exception:
             print("FAILED", name, out.stderr[-500:])
 for name in args.names:

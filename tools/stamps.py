@@ -31,13 +31,20 @@ for rep in range(20):
     t0 = s[:, 0].min()
     rows.append((s, t0))
 s, t0 = rows[-1]
-print("worlds %d, wavefronts %d; s_memtime ticks (100 MHz constant clock? see below)" % (n, waves))
-print("span of kernel (first stamp0 -> last stamp7): %.0f ticks" % (s[:, 7].max() - t0))
-for i in range(8):
-    rel = s[:, i] - t0
-    print("stamp %d: min %8.0f  median %8.0f  p99 %8.0f  max %8.0f" % (i, rel.min(), np.median(rel), np.percentile(rel, 99), rel.max()))
-for i in range(7):
+# slots 0 and 7 are s_memrealtime (100 MHz wall clock, common to all XCDs); 1..6 are s_memtime (shader clock, per XCD)
+span = (s[:, 7].max() - s[:, 0].min()) * 10e-3
+print("worlds %d, wavefronts %d" % (n, waves))
+print("first wave start -> last wave end (wall): %.2f us; per-wave lifetime: median %.2f us, p90 %.2f, max %.2f" %
+      (span, np.median(s[:, 7] - s[:, 0]) * 1e-2, np.percentile(s[:, 7] - s[:, 0], 90) * 1e-2, (s[:, 7] - s[:, 0]).max() * 1e-2))
+print("start skew (first -> last wave start): %.2f us" % ((s[:, 0].max() - s[:, 0].min()) * 1e-2))
+blk = s.reshape(-1, 16, 8)
+print("per-block lifetime (first start -> last end): median %.2f us  p90 %.2f  max %.2f" %
+      (np.median(blk[:, :, 7].max(1) - blk[:, :, 0].min(1)) * 1e-2, np.percentile(blk[:, :, 7].max(1) - blk[:, :, 0].min(1), 90) * 1e-2,
+       (blk[:, :, 7].max(1) - blk[:, :, 0].min(1)).max() * 1e-2))
+names2 = ["philox->fast path", "fast->exact", "exact->outputs+list", "list->barrier", "barrier->group reseed"]
+for i in range(1, 6):
     d = s[:, i + 1] - s[:, i]
-    print("%-28s median %7.0f  p90 %7.0f  p99 %7.0f  max %7.0f" % (names[i], np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max()))
-spans = [r[0][:, 7].max() - r[1] for r in rows]
-print("kernel span over 20 launches: median %.0f min %.0f max %.0f ticks" % (np.median(spans), min(spans), max(spans)))
+    print("%-28s median %7.0f  p90 %7.0f  p99 %7.0f  max %7.0f  (shader cycles)" % (names2[i - 1], np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max()))
+cyc = (s[:, 6] - s[:, 1])
+wall = (s[:, 7] - s[:, 0]) * 10.0
+print("shader clock estimate: %.2f GHz (cycles 1->6 over wall 0->7, lower bound)" % np.median(cyc / wall))
