@@ -75,7 +75,12 @@ class BatchedAqua(object):
         self.num_envs = int(num_envs)
         self.env_offset = int(env_offset)
         self.continuous = bool(continuous)
-        self.auto_reset = bool(auto_reset)
+        # restart of finished worlds: False/0 never (the reference's behaviour), True/1/"same_step" inside the
+        # launch that finished them, 2/"next_step" during the next step (Gymnasium >= 1.0 convention, fastest)
+        modes = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, "none": 0, "same_step": 1, "next_step": 2}
+        if auto_reset not in modes:
+            raise ValueError("auto_reset must be False, True, 'same_step' or 'next_step'")
+        self.auto_reset = modes[auto_reset]
         self.has_waves = int(waves)                   # aqua.py:15
         self.seed = int(seed) if seed is not None else int(np.random.SeedSequence().entropy & ((1 << 64) - 1))
         self.obstacle_rows = presets.rows_from(obstacles)

@@ -259,7 +259,15 @@ __device__ __forceinline__ ExactMotion exact_motion_continuous(double vl, double
     return m;
 }
 
-__device__ __noinline__ ExactOut exact_step(float fx, float fy, float fth, float fgx, float fgy, float fwx,
+#ifndef AQUA_INLINE_EXACT
+#define AQUA_INLINE_EXACT 0
+#endif
+#if AQUA_INLINE_EXACT
+#define AQUA_EXACT_ATTR __forceinline__
+#else
+#define AQUA_EXACT_ATTR __noinline__
+#endif
+__device__ AQUA_EXACT_ATTR ExactOut exact_step(float fx, float fy, float fth, float fgx, float fgy, float fwx,
                                             float fwy, int t_new, ExactMotion mo, int K,
                                             const double* __restrict__ obst64, ObstPtr obst32, float band2,
                                             int time_limit)

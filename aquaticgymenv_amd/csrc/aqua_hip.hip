@@ -514,6 +514,123 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
     step_tile<VEC, AK>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
+// ------------------------------------------------------------------ one launch per step, next-step restart
+// auto_reset == 2 ("next-step", the Gymnasium >= 1.0 convention): a world that finishes at tick t keeps its
+// terminal state, is marked pending (time = -1) and is restarted DURING tick t + 1, when it does not step:
+// that tick reports its fresh observation with reward 0 and term 0.  Nothing of the restart is then on the
+// step's dependency chain, so the re-seeding runs beside the main work instead of behind it: a workgroup
+// is NS_MAIN_WAVES wavefronts that step NS_TILE worlds plus NS_WORK_WAVES dedicated wavefronts that
+// re-seed the tile's pending worlds.  Main wavefronts load `time` first, append their pending worlds to
+// the LDS list, signal arrival (LDS counter, no barrier) and carry on; the workers wait for the last
+// arrival only.
+constexpr int NS_MAIN_WAVES = 6, NS_WORK_WAVES = 2;
+constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = (NS_MAIN_WAVES + NS_WORK_WAVES) * 64;
+
+struct NsShared {
+    uint32_t count, arrived;
+    uint16_t list[NS_TILE];
+};
+
+template <int AK>
+__global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
+{
+    AQUA_OBST_DECL
+    __shared__ NsShared sh;
+    if (threadIdx.x == 0) { sh.count = 0; sh.arrived = 0; }
+    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    __syncthreads();                                  // nothing has happened yet: every wavefront is here at once
+    const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * NS_TILE;
+    const int64_t ld = a.ld, rem = a.N - tile;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* const row0 = a.state + tile;
+    int32_t* const trow = a.time + tile;
+
+    if (wave >= NS_MAIN_WAVES) {
+        // ---- worker wavefront: re-seed the worlds that finished last tick
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&sh.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                   static_cast<uint32_t>(NS_MAIN_WAVES) && spins < (1u << 22)) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+        }
+        const uint32_t n_pending = sh.count;
+        constexpr uint32_t GROUPS = NS_WORK_WAVES * (64 / RESET_GROUP);
+        for (uint32_t qb = (wave - NS_MAIN_WAVES) * (64 / RESET_GROUP); qb < n_pending; qb += GROUPS) {
+            const uint32_t q = qb + (lane / RESET_GROUP);
+            const bool active = q < n_pending;
+            const uint32_t i = sh.list[active ? q : 0];
+            const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
+                                                            tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                row0[0 * ld + i] = e.x; row0[1 * ld + i] = e.y; row0[2 * ld + i] = e.th;
+                row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
+                row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
+                trow[i] = e.t;
+            }
+        }
+        return;
+    }
+
+    // ---- main wavefront
+    const uint32_t off = threadIdx.x;                  // < NS_TILE
+    const bool valid = static_cast<int64_t>(off) < rem;
+    int32_t t0 = valid ? trow[off] : 0;
+    const bool pending = valid && t0 < 0;
+    if (pending) sh.list[atomicAdd(&sh.count, 1u)] = static_cast<uint16_t>(off);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&sh.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+    float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
+    int32_t tdummy[1];
+    int aidx[1] = {2};
+    if (rem >= NS_TILE) load_inputs<1, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, tdummy, aidx, avl, avr, u0, u1);
+    else load_inputs<1, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, tdummy, aidx, avl, avr, u0, u1);
+
+    const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
+    if (a.noise == nullptr) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
+        u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
+    }
+    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
+        if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
+        else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
+    }
+    const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
+    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
+    const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
+    float rew;
+    uint32_t code;
+    const bool live = valid && !pending;
+    const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
+    if (__any(knife)) {
+        if (knife) {
+            const ExactOut o = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
+                                          k.obst, k.band2, k.time_limit);
+            e.x = o.x; e.y = o.y; e.th = o.th; rew = o.reward; code = o.term;
+        }
+    }
+    if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
+    const bool done = code != 0u;
+    if (valid) {
+        a.reward[tile + off] = rew;
+        a.term[tile + off] = static_cast<uint8_t>(code);
+    }
+    if (a.done_bits != nullptr) {
+        const uint64_t b = __ballot(done);
+        const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
+    }
+    if (live) {                                        // pending worlds are written by the workers
+        row0[0 * ld + off] = e.x; row0[1 * ld + off] = e.y; row0[2 * ld + off] = e.th;
+        row0[5 * ld + off] = e.wx; row0[6 * ld + off] = e.wy;
+        trow[off] = done ? -1 : e.t;
+    }
+}
+
 // ------------------------------------------------------------------ T steps in one launch
 template <int AK>
 __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
@@ -692,8 +809,26 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     return hipGetLastError();
 }
 
+hipError_t launch_step_ns(const StepArgs& a, int kind, hipStream_t s)
+{
+    const int64_t tiles = (a.N + NS_TILE - 1) / NS_TILE;
+    if (tiles > MAX_GRID) return hipErrorInvalidValue;
+    const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
+    switch (kind) {
+        case AQUA_ACT_U8: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_U8>), grid, block, 0, s, a); break;
+        case AQUA_ACT_I32: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_I32>), grid, block, 0, s, a); break;
+        case AQUA_ACT_I64: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_I64>), grid, block, 0, s, a); break;
+        case AQUA_ACT_F32X2: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
+        case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
+        case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_step_any(const StepArgs& a, int kind, int vec, hipStream_t s)
 {
+    if (a.auto_reset == AQUA_RESET_NEXT_STEP) return launch_step_ns(a, kind, s);
     if (vec == 4) return launch_step<4>(a, kind, s);
     if (vec == 2) return launch_step<2>(a, kind, s);
     return launch_step<1>(a, kind, s);
@@ -812,6 +947,7 @@ int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t
     rc = check_step_buffers(N, action, action_kind, action_ld, noise, noise_ld, reward, term);
     if (rc) return rc;
     if (done_bits != nullptr && !aligned(done_bits, 8)) return fail(AQUA_E_ALIGN, "done_bits must be 8-byte aligned");
+    if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
     if (N == 0) return 0;
     a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
     a.reward = reward; a.term = term; a.done_bits = done_bits; a.auto_reset = auto_reset;

@@ -56,6 +56,11 @@ extern "C" {
 #define AQUA_TERM_TIME     2    /* 'Termination.time'     */
 #define AQUA_TERM_SUCCESS  3    /* 'Termination.success'  */
 
+/* auto_reset modes of aqua_step_f32 / aqua_rollout_f32 */
+#define AQUA_RESET_NONE      0  /* the reference's behaviour: no freeze, no restart (the caller resets) */
+#define AQUA_RESET_SAME_STEP 1  /* a finished world is restarted inside the launch that finished it */
+#define AQUA_RESET_NEXT_STEP 2  /* ... during the NEXT step, in which it does not move (reward 0, term 0) */
+
 #define AQUA_MAX_OBSTACLES 64
 
 /* Constructor arguments of the reference's AquaEnv (aqua.py:13-31) that change the arithmetic. */
@@ -93,9 +98,14 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
  *                   it on the device so a captured graph can be replayed with fresh noise.
  *   reward        : float32[N]; term: uint8[N] (AQUA_TERM_*); done_bits: uint64[ceil(N/64)] or NULL,
  *                   bit (i % 64) of word (i / 64) = done flag of local world i (wavefront ballot).
- *   auto_reset    : != 0 -> worlds that finished are re-initialised in the same launch exactly as
- *                   aqua_reset_f32(mask = term != 0) would; reward/term/done_bits still describe the
- *                   step that finished.  == 0 -> the reference's behaviour: no freeze, no reset.
+ *   auto_reset    : AQUA_RESET_NONE      -> the reference's behaviour: no freeze, no reset.
+ *                   AQUA_RESET_SAME_STEP -> worlds that finished are re-initialised in the same launch exactly as
+ *                   aqua_reset_f32(mask = term != 0) would; reward/term/done_bits still describe the step
+ *                   that finished; the observation is already the new episode's.
+ *                   AQUA_RESET_NEXT_STEP -> (Gymnasium >= 1.0 convention, the fastest mode) a world that finishes
+ *                   at tick t keeps its terminal state, time[i] = -1 marks it, and the launch of tick t + 1
+ *                   re-initialises it instead of stepping it: that tick reports the fresh observation with
+ *                   reward 0 and term 0.
  */
 int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
                   float* state, int64_t ld, int32_t* time, const void* action, int action_kind,

@@ -28,6 +28,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #ifdef _OPENMP
@@ -361,11 +362,19 @@ int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves,
     int64_t episodes = 0, c1 = 0, c2 = 0, c3 = 0;
     for (int64_t t = 0; t < steps; ++t) {
         uint64_t tick = tick0 + (uint64_t)t;
+        /* auto_reset == 2 ("next-step"): worlds marked pending (time == -1) at the start of the tick do not
+         * step; they are re-initialised during this tick and report reward 0, term 0 */
+        uint8_t* pending = NULL;
+        if (auto_reset == 2) {
+            pending = (uint8_t*)malloc((size_t)n);
+            for (int64_t i = 0; i < n; ++i) pending[i] = time[i] < 0;
+        }
 #pragma omp parallel for schedule(static) reduction(+ : episodes, c1, c2, c3)
         for (int64_t i = 0; i < n; ++i) {
             double s[7], u[2], vl, vr, rew;
             uint32_t raw[4], aw[2];
             uint8_t code;
+            if (pending && pending[i]) { reward[i] = 0.0f; term[i] = 0; continue; }
             for (int j = 0; j < 7; ++j) s[j] = (double)state[j * ld + i];
             aqua_oracle_step_noise(seed, (uint64_t)(env_offset + i), tick, u, raw);
             if (actions) {
@@ -387,9 +396,16 @@ int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves,
             reward[i] = (float)rew;
             term[i] = code;
             if (code) { episodes++; c1 += code == 1; c2 += code == 2; c3 += code == 3; }
+            if (code && auto_reset == 2) {
+                time[i] = -1;                           /* pending: goal stays, pose/wave are the terminal ones */
+            }
         }
-        if (auto_reset)
+        if (auto_reset == 1)
             aqua_oracle_reset(n, K, obst, waves, 1, 1, seed, tick, env_offset, term, state, ld, time);
+        if (auto_reset == 2) {
+            aqua_oracle_reset(n, K, obst, waves, 1, 1, seed, tick, env_offset, pending, state, ld, time);
+            free(pending);
+        }
     }
     if (term_counts) { term_counts[0] = c1; term_counts[1] = c2; term_counts[2] = c3; }
     return episodes;

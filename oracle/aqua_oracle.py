@@ -153,7 +153,8 @@ class COracle(object):
 
     def rollout_f32(self, state, time, steps, obstacles=None, waves=1, continuous=False, actions=None, seed=0,
                     tick0=0, env_offset=0, auto_reset=True):
-        """float32-state rollout (state [7][ld], in place).  actions None -> sampled from the step draw.
+        """float32-state rollout (state [7][ld], in place).  actions None -> sampled from Philox stream 4.
+        auto_reset: False/0 none, True/1 same-step restart, 2 next-step restart (pending worlds: time == -1).
         Returns (episodes, reward f32[n] of the last step, term u8[n] of the last step, term_counts[3])."""
         assert state.dtype == np.float32 and state.flags.c_contiguous
         n = time.shape[0]

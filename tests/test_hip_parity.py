@@ -164,14 +164,18 @@ def test_step_matches_oracle_philox(torch, oracle, vec, n, continuous, obst):
         _compare_with_oracle(torch, oracle, env, state0, time0, a_or, reward.cpu().numpy(), term.cpu().numpy(), tick)
 
 
-def test_sampled_actions_match_oracle_rollout(torch, oracle):
-    """device-sampled actions + auto-reset, 40 steps, against the oracle's float32-state rollout:
-    teacher-forced per step (the oracle restarts from the kernel's state every step)."""
+@pytest.mark.parametrize("mode", [1, 2], ids=["same_step", "next_step"])
+def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
+    """device-sampled actions + restart of finished worlds, 40 steps, against the oracle's float32-state
+    rollout: teacher-forced per step (the oracle restarts from the kernel's state every step).
+    mode 1: finished worlds are re-seeded in the launch that finished them; mode 2 (next-step): they are
+    marked pending (time == -1) and re-seeded during the next step, which reports reward 0 / term 0."""
     from aquaticgymenv_amd import presets
-    n = 8192
+    n = 8192 + 37
     for continuous in (False, True):
-        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=99, auto_reset=True)
+        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=99, auto_reset=mode)
         env.reset()
+        finished = 0
         for it in range(40):
             s0, t0 = _host_state(env)
             tick = env._tick
@@ -181,21 +185,26 @@ def test_sampled_actions_match_oracle_rollout(torch, oracle):
             tt = t0.copy()
             ep, o_rew, o_term, counts = oracle.rollout_f32(st, tt, 1, obstacles=env.obstacle_rows, waves=1,
                                                             continuous=continuous, seed=env.seed, tick0=tick,
-                                                            auto_reset=True)
+                                                            auto_reset=mode)
             k_state, k_time = _host_state(env)
             term_h, rew_h = term.cpu().numpy(), reward.cpu().numpy()
             assert np.array_equal(term_h, o_term)
             assert np.max(np.abs(rew_h - o_rew)) <= TOL
-            done = o_term != 0
-            # worlds that restarted: float32 reset specification, bit for bit
-            assert np.array_equal(k_state[:, done], st[:, done])
             assert np.array_equal(k_time, tt)
-            live = ~done
+            assert np.array_equal(env.done_mask().cpu().numpy(), (o_term != 0).astype(np.uint8))
+            reseeded = (o_term != 0) if mode == 1 else (t0 < 0)
+            # worlds that restarted: float32 reset specification, bit for bit
+            assert np.array_equal(k_state[:, reseeded], st[:, reseeded])
+            if mode == 2:
+                assert np.all(rew_h[reseeded] == 0) and np.all(term_h[reseeded] == 0) and np.all(k_time[reseeded] == 0)
+                assert np.all(k_time[o_term != 0] == -1)
+            live = ~reseeded
             assert np.max(np.abs(k_state[0:2, live] - st[0:2, live])) <= TOL
             assert np.max(angle_diff(k_state[2, live], st[2, live])) <= TOL
             assert np.max(np.abs(k_state[5:7, live] - st[5:7, live])) <= 1e-7
             assert np.array_equal(k_state[3:5, live], st[3:5, live])
-        assert ep >= 0
+            finished += int((o_term != 0).sum())
+        assert finished > n // 4
 
 
 # ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ from aquaticgymenv_amd import presets, _capi
 from aquaticgymenv_amd.batched import BatchedAqua
 _capi.lib.aqua_set_vector_width(int(os.environ.get("AQUA_VEC", "0")))
 n, steps = %d, %d
-env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=True, device="cuda:0")
+env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=int(os.environ.get("AQUA_RESET_MODE", "1")), device="cuda:0")
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 acts = torch.randint(0, 3, (100, env.ld), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
@@ -45,14 +45,16 @@ for r in range(args.rounds):
     for name in args.names:
         env = dict(os.environ)
         name, _, vec = name.partition(":")
+        name, _, mode = name.partition("@")
         env["AQUA_VEC"] = vec or "0"
+        env["AQUA_RESET_MODE"] = mode or "1"
         if name != "default":
             env["AQUA_HIP_LIB"] = os.path.join(ROOT, "aquaticgymenv_amd", "lib", "variants", "libaqua_hip_%s.so" % name)
         else:
             env.pop("AQUA_HIP_LIB", None)
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
         try:
-            res[name + (":" + vec if vec else "")].append(float(out.stdout.strip().splitlines()[-1]))
+            res[name + ("@" + mode if mode else "") + (":" + vec if vec else "")].append(float(out.stdout.strip().splitlines()[-1]))
         except Exception:
             print("FAILED", name, out.stderr[-500:])
 for name in args.names:
