@@ -60,8 +60,8 @@ def build_variant(name, flags, verbose=False):
 
 if __name__ == "__main__":
     if "--variants" in sys.argv:
-        for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("tile512", ["-DAQUA_TILE=512"]),
-                            ("tile1024_lds", ["-DAQUA_OBST_LDS=1"]), ("group4", ["-DAQUA_RESET_GROUP=4"]),
-                            ("group16", ["-DAQUA_RESET_GROUP=16"]), ("stamps", ["-DAQUA_STAMPS=1"]), ("inlexact", ["-DAQUA_INLINE_EXACT=1"]), ("inlexact_stamps", ["-DAQUA_INLINE_EXACT=1", "-DAQUA_STAMPS=1"])):
+        for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("lds", ["-DAQUA_OBST_LDS=1"]),
+                            ("group4", ["-DAQUA_RESET_GROUP=4"]), ("group16", ["-DAQUA_RESET_GROUP=16"]),
+                            ("stamps", ["-DAQUA_STAMPS=1"]), ("noprio", ["-DAQUA_WORKER_PRIO=0"])):
             print(build_variant(name, flags, verbose=True))
     print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -129,27 +129,15 @@ __device__ __forceinline__ float u_01(uint32_t r)      // [0, 1)
 }
 
 // ------------------------------------------------------------------------------------ math
-// sin and cos of a bounded argument (|a| <= pi + 0.06 in normal operation): Cody-Waite reduction
-// by pi/2 and degree-7/8 minimax polynomials; abs error < 1.2e-7.  Huge arguments (only possible
-// when a caller writes a wild theta into the state) go to the library routine.
+// sin and cos on the transcendental unit: v_sin_f32 / v_cos_f32 take their argument in revolutions.
+// Measured on MI355X over [-3.3, 3.3] rad (tools/micro/vsin_acc.hip): max abs error 3.5e-7 / 2.5e-7, i.e.
+// < 2e-7 world units on the chord -- well inside the 1e-5 budget whose bulk is the float32 rounding of x', y'
+// themselves (3.8e-6).  v_fract first keeps any theta a caller may have written inside the unit's domain.
 __device__ __forceinline__ void sincos_bounded(float a, float& s, float& c)
 {
-    if (__builtin_expect(fabsf(a) > 64.0f, 0)) { s = sinf(a); c = cosf(a); return; }
-    const float k = rintf(a * 0.636619772367581343f);
-    float r = fmaf(k, -1.5707962512969971f, a);            // pi/2 hi
-    r = fmaf(k, -7.5497894158615964e-08f, r);              // pi/2 lo
-    const float r2 = r * r;
-    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = fmaf(sp, r2, -1.6666654611e-1f);
-    const float sr = fmaf(r * r2, sp, r);
-    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = fmaf(cp, r2, 4.166664568298827e-2f);
-    const float cr = fmaf(r2 * r2, cp, fmaf(r2, -0.5f, 1.0f));
-    const int q = static_cast<int>(k) & 3;
-    const float s0 = (q & 1) ? cr : sr;
-    const float c0 = (q & 1) ? sr : cr;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
+    const float rev = __builtin_amdgcn_fractf(a * 0.15915494309189535f);
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
 }
 
 // theta <- theta + w folded into [-pi, pi) (aqua.py:128-133).  The float32 neighbours of +-pi are

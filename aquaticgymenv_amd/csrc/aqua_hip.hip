@@ -219,6 +219,9 @@ __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u
 #ifndef AQUA_WAVE_RESET
 #define AQUA_WAVE_RESET 0
 #endif
+#ifndef AQUA_WORKER_PRIO
+#define AQUA_WORKER_PRIO 1
+#endif
 
 #if AQUA_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
@@ -548,6 +551,9 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 
     if (wave >= NS_MAIN_WAVES) {
         // ---- worker wavefront: re-seed the worlds that finished last tick
+#if AQUA_WORKER_PRIO
+        __builtin_amdgcn_s_setprio(3);      // the worker's chain is the longest in the workgroup: let it issue first
+#endif
         uint32_t spins = 0;
         while (__hip_atomic_load(&sh.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
                    static_cast<uint32_t>(NS_MAIN_WAVES) && spins < (1u << 22)) {

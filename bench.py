@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--continuous", action="store_true", help="configs[3]: continuous actions")
     ap.add_argument("--no-obstacles", action="store_true", help="configs[1]-style: no obstacles")
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: finished worlds are not restarted")
+    ap.add_argument("--reset-mode", type=int, default=2, choices=(1, 2),
+                    help="restart of finished worlds: 2 = during the next step (default, fastest), 1 = inside the same launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
@@ -116,7 +118,7 @@ def main():
     n = args.envs
     obstacles = presets.NONE if args.no_obstacles else presets.BENCH8
     env = BatchedAqua(n, obstacles=obstacles, continuous=args.continuous, seed=0, env_offset=rank * n,
-                      auto_reset=not args.no_auto_reset, device=dev)
+                      auto_reset=0 if args.no_auto_reset else args.reset_mode, device=dev)
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     if args.continuous:
@@ -172,9 +174,10 @@ def main():
             "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch %d worlds/GPU, %s actions, %s, waves on, auto-reset, HIP graph of %d steps"
+            "config": {"workload": "batch %d worlds/GPU, %s actions, %s, waves on, auto-reset (%s), HIP graph of %d steps"
                        % (n, "continuous f32x2" if args.continuous else "discrete u8",
-                          "no obstacles" if args.no_obstacles else "4 circle + 4 rect obstacles", CHUNK),
+                          "no obstacles" if args.no_obstacles else "4 circle + 4 rect obstacles",
+                          "off" if args.no_auto_reset else ("next-step" if args.reset_mode == 2 else "same-step"), CHUNK),
                        "baseline_config": "configs[3]" if args.continuous else ("configs[1]-like" if args.no_obstacles else "configs[2]"),
                        "worlds_per_gpu": n, "global_worlds": world * n, "parallelism": "range-partition x%d" % world,
                        "launch": "eager" if args.eager else "hipGraph"},
