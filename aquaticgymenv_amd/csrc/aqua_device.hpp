@@ -479,7 +479,10 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
         const float cbx = fmaf(95.0f, u_01(rp[2]), 2.5f), cby = fmaf(95.0f, u_01(rp[3]), 2.5f);
         // one pass over the obstacle table tests both candidates of this attempt
         bool hit_g = false, hit_b = false;
-#pragma unroll 2
+#ifndef AQUA_RESEED_UNROLL
+#define AQUA_RESEED_UNROLL 2
+#endif
+#pragma unroll AQUA_RESEED_UNROLL
         for (int j = 0; j < K; ++j) {
             const float cx = t[j].cx, cy = t[j].cy, hx = t[j].hx, hy = t[j].hy, r2 = t[j].r2;
             const float gax = fabsf(cgx - cx), gay = fabsf(cgy - cy);

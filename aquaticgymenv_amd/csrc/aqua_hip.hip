@@ -551,6 +551,9 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 
     if (wave >= NS_MAIN_WAVES) {
         // ---- worker wavefront: re-seed the worlds that finished last tick
+#ifdef AQUA_NS_NOWORK
+        return;                              // timing experiment only
+#endif
 #if AQUA_WORKER_PRIO
         __builtin_amdgcn_s_setprio(3);      // the worker's chain is the longest in the workgroup: let it issue first
 #endif
@@ -638,6 +641,35 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 }
 
 // ------------------------------------------------------------------ T steps in one launch
+// State stays in registers for the whole rollout; per world-step only the action is read and reward/term
+// are written.  Finished worlds are re-seeded inside the wavefront: the lanes that need it are handed, eight
+// at a time, to the eight 8-lane groups of the wavefront (reset_env_group) and get their fresh state back by
+// shuffle.  Both restart conventions are supported and give exactly the per-step kernels' results.
+__device__ __forceinline__ void wave_reseed(EnvState& e, bool need, const StepArgs& a, const StepConst& k, uint64_t tick,
+                                            int64_t wave_first_world)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(need);
+    while (m != 0) {
+        int owner = -1, src = lane;
+        bool mine = false;
+#pragma unroll
+        for (int g = 0; g < 64 / RESET_GROUP; ++g) {
+            const int o = m ? static_cast<int>(__builtin_ctzll(m)) : -1;
+            if (lane / RESET_GROUP == g) owner = o;
+            if (o == lane) { src = g * RESET_GROUP; mine = true; }
+            m &= m - 1;
+        }
+        const bool active = owner >= 0;
+        const uint64_t env = static_cast<uint64_t>(a.env_offset + wave_first_world) + static_cast<uint64_t>(active ? owner : 0);
+        const EnvState f = reset_env_group<RESET_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K,
+                                                        k.obst);
+        const float fx = __shfl(f.x, src), fy = __shfl(f.y, src), fth = __shfl(f.th, src), fgx = __shfl(f.gx, src),
+                    fgy = __shfl(f.gy, src), fwx = __shfl(f.wx, src), fwy = __shfl(f.wy, src);
+        if (mine) { e.x = fx; e.y = fy; e.th = fth; e.gx = fgx; e.gy = fgy; e.wx = fwx; e.wy = fwy; e.t = 0; }
+    }
+}
+
 template <int AK>
 __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
 {
@@ -645,21 +677,28 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
     const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick0 = a.tick + (a.tick_base ? *a.tick_base : 0ull);
     const int64_t N = a.N, ld = a.ld;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
-         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
-        EnvState e{a.state[0 * ld + i], a.state[1 * ld + i], a.state[2 * ld + i], a.state[3 * ld + i],
-                   a.state[4 * ld + i], a.state[5 * ld + i], a.state[6 * ld + i], a.time[i]};
-        const uint64_t env = static_cast<uint64_t>(a.env_offset + i);
+    // whole wavefronts iterate together (ballots and shuffles inside); lanes past N are inert
+    for (int64_t wbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + (threadIdx.x & ~63); wbase < N;
+         wbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+        const int64_t i = wbase + (threadIdx.x & 63);
+        const bool valid = i < N;
+        const int64_t ic = valid ? i : N - 1;
+        EnvState e{a.state[0 * ld + ic], a.state[1 * ld + ic], a.state[2 * ld + ic], a.state[3 * ld + ic],
+                   a.state[4 * ld + ic], a.state[5 * ld + ic], a.state[6 * ld + ic], a.time[ic]};
+        const uint64_t env = static_cast<uint64_t>(a.env_offset + ic);
         for (int64_t s = 0; s < a.T; ++s) {
             const uint64_t tick = tick0 + static_cast<uint64_t>(s);
+            // next-step restart: a world marked pending does not move this tick, it is re-seeded instead
+            const bool pending = a.auto_reset == AQUA_RESET_NEXT_STEP && valid && e.t < 0;
+            if (a.auto_reset == AQUA_RESET_NEXT_STEP && __any(pending)) wave_reseed(e, pending, a, k, tick, wbase);
             int idx = 2;
             float vl = 0.5f, vr = 0.5f;
-            if constexpr (AK == AQUA_ACT_U8) idx = fold_index(static_cast<const uint8_t*>(a.action)[s * a.action_step_stride + i]);
-            if constexpr (AK == AQUA_ACT_I32) idx = fold_index(static_cast<const int32_t*>(a.action)[s * a.action_step_stride + i]);
-            if constexpr (AK == AQUA_ACT_I64) idx = fold_index(static_cast<const int64_t*>(a.action)[s * a.action_step_stride + i]);
+            if constexpr (AK == AQUA_ACT_U8) idx = fold_index(static_cast<const uint8_t*>(a.action)[s * a.action_step_stride + ic]);
+            if constexpr (AK == AQUA_ACT_I32) idx = fold_index(static_cast<const int32_t*>(a.action)[s * a.action_step_stride + ic]);
+            if constexpr (AK == AQUA_ACT_I64) idx = fold_index(static_cast<const int64_t*>(a.action)[s * a.action_step_stride + ic]);
             if constexpr (AK == AQUA_ACT_F32X2) {
                 const float* base = static_cast<const float*>(a.action) + s * a.action_step_stride;
-                vl = base[i]; vr = base[a.action_ld + i];
+                vl = base[ic]; vr = base[a.action_ld + ic];
             }
             uint32_t w0[1], w1[1];
             pair_draws<1, false>(a.seed, env, tick, STREAM_STEP, w0, w1);
@@ -671,27 +710,34 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
             }
             const Motion m = decode_motion<AK>(k, idx, vl, vr);
             const EnvState before = e;
+            EnvState after = e;
             float rew;
             uint32_t code;
-            const bool knife = fast_step(e, m.h, m.w, m.chord, u0, u1, k, rew, code);
+            const bool knife = fast_step(after, m.h, m.w, m.chord, u0, u1, k, rew, code) && valid && !pending;
             if (__any(knife)) {
                 if (knife) {
                     const ExactOut o = exact_step(before.x, before.y, before.th, before.gx, before.gy, before.wx,
-                                                  before.wy, e.t, exact_motion<AK>(m), k.K, k.obst64, k.obst, k.band2,
+                                                  before.wy, after.t, exact_motion<AK>(m), k.K, k.obst64, k.obst, k.band2,
                                                   k.time_limit);
-                    e.x = o.x; e.y = o.y; e.th = o.th; rew = o.reward; code = o.term;
+                    after.x = o.x; after.y = o.y; after.th = o.th; rew = o.reward; code = o.term;
                 }
             }
-            a.reward[s * a.out_step_stride + i] = rew;
-            a.term[s * a.out_step_stride + i] = static_cast<uint8_t>(code);
-            if (a.auto_reset && __any(code != 0)) {
-                if (code != 0) e = reset_env(a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            if (pending) { rew = 0.0f; code = 0u; }          // the restart tick reports reward 0, term 0
+            else e = after;
+            if (valid) {
+                a.reward[s * a.out_step_stride + i] = rew;
+                a.term[s * a.out_step_stride + i] = static_cast<uint8_t>(code);
             }
+            const bool done = valid && code != 0u;
+            if (a.auto_reset == AQUA_RESET_SAME_STEP) { if (__any(done)) wave_reseed(e, done, a, k, tick, wbase); }
+            else if (a.auto_reset == AQUA_RESET_NEXT_STEP && done) e.t = -1;
         }
-        a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
-        a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
-        a.state[5 * ld + i] = e.wx; a.state[6 * ld + i] = e.wy;
-        a.time[i] = e.t;
+        if (valid) {
+            a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
+            a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
+            a.state[5 * ld + i] = e.wx; a.state[6 * ld + i] = e.wy;
+            a.time[i] = e.t;
+        }
     }
 }
 
@@ -928,6 +974,45 @@ void aqua_discrete_constants(float out[9])
 }
 
 #if AQUA_STAMPS
+// micro-benchmark (diagnostic build only): cycles of one warm call of the re-seeding group routine and of
+// one warm Philox draw, executed by a single wavefront that has the SIMD to itself
+__global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, int iters)
+{
+    AQUA_OBST_DECL
+    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    float acc = 0.0f;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    for (int rep = 0; rep < 2; ++rep) {          // rep 0 warms the instruction and scalar caches
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        for (int it = 0; it < iters; ++it) {
+            const EnvState e = reset_env_group<RESET_GROUP>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
+                                                            a.tick + it, k.waves, 1, 1, k.K, k.obst);
+            acc += e.x + e.gy;
+        }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        for (int it = 0; it < iters; ++it) {
+            uint32_t r[4];
+            draw(a.seed, threadIdx.x + 64ull * it, a.tick, STREAM_PLACE, 0, r);
+            acc += u_01(r[0] ^ r[3]);
+        }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+    }
+    if (threadIdx.x == 0) { out[0] = (t1 - t0) / iters; out[1] = (t2 - t1) / iters; }
+    if (acc == 12345.678f) out[2] = 1;
+}
+
+int aqua_debug_reseed_bench(const AquaParams* p, const void* blob, int K, unsigned long long* out_dev, void* stream)
+{
+    StepArgs a;
+    float dummy_state = 0.0f;
+    int32_t dummy_time = 0;
+    const int rc = fill_args(a, p, blob, K, 1, 0, &dummy_state, 1, &dummy_time, 12345, 7, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reseed_bench_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a, out_dev, 200);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "reseed bench");
+}
+
 int aqua_debug_set_stamps(unsigned long long* dev_ptr)
 {
     const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_ptr, sizeof(dev_ptr));

@@ -187,6 +187,7 @@ def main():
                          "note": "launch_us = HIP-event time of the timed region / launches (includes the "
                                  "inter-kernel boundary); kernel-only duration: profiles/"},
         }
+        result["roofline"]["traffic"] = committed_traffic(n, args)
         if world == 1 and not args.no_cpu_baseline:
             base, c = cpu_baseline(args, obstacles)
             result["cpu_baseline"] = base
@@ -200,11 +201,28 @@ def main():
     return result
 
 
+def committed_traffic(n, args):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate passes, KB -> bytes, FETCH_SIZE doubled: on gfx950 it reports half of a
+    coalesced stream, MI355X_MICROARCH.md "HBM").  null when no profile matches this configuration."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except Exception:
+        return None
+    key = "n%d_%s_%s" % (n, "cont" if args.continuous else "disc", "k0" if args.no_obstacles else "k8")
+    row = table.get(key)
+    if not row:
+        return None
+    return 2.0 * row["FETCH_SIZE_per_launch_raw"] * 1024.0 + row["WRITE_SIZE_per_launch_raw"] * 1024.0
+
+
 def extras(env, torch, n, a_bytes):
     """separate lines that must not be mixed into `value`: the fused multi-step kernel (state in
-    registers: 6 B per world-step: action 1 + reward 4 + term 1) with device-sampled actions."""
+    registers: 5 B per world-step: reward 4 + term 1, actions sampled on the device)."""
     out = {}
-    T = 1000
+    T = 2000
     env.rollout(T, fused=True, keep_all=False)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -214,7 +232,8 @@ def extras(env, torch, n, a_bytes):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     out["fused_rollout"] = {"env_steps_per_s": n * T / (ms * 1e-3), "steps": T, "bytes_per_world_step": 5,
-                            "actions": "sampled on device", "ms": ms}
+                            "us_per_step": ms * 1e3 / T, "actions": "sampled on device",
+                            "note": "ONE launch for all steps, state in registers: the issue-bound floor of this arithmetic"}
     return out
 
 

@@ -10,7 +10,10 @@ num_envs == 1  -> reference-shaped returns: reset() -> float64[5]; step(a) -> (f
                   auto-reset, no freeze after done (the caller resets, as main/impl/dqn.py:150 does).
 num_envs  > 1  -> device tensors: obs [N,5] float32 (a strided VIEW of the state rows), reward [N]
                   float32, done [N] bool, info = the same three keys holding bool tensors [N]
-                  (plus 'term': uint8 codes).  Finished worlds restart inside the same launch.
+                  (plus 'term': uint8 codes).  Finished worlds restart by themselves; `autoreset` picks the
+                  convention: "next_step" (default, Gymnasium >= 1.0: the world restarts during the NEXT
+                  step, which returns the fresh observation with reward 0 / done False; fastest) or
+                  "same_step" (classic gym VectorEnv: the returned observation is already the new episode's).
 All arithmetic happens in libaqua_hip.so; there is no CPU implementation behind this class.
 """
 import math
@@ -57,7 +60,7 @@ class AquaEnv(_EnvBase):
     continuous = False
 
     def __init__(self, obstacles=False, waves=True, random_boat=True, random_goal=True, num_envs=1, device=None,
-                 seed=None):
+                 seed=None, autoreset="next_step"):
         self.has_waves = int(waves)
         self.random_boat = random_boat
         self.random_goal = random_goal
@@ -85,7 +88,7 @@ class AquaEnv(_EnvBase):
         self.obstacles = presets.as_reference_list(rows)
         self.core = BatchedAqua(self.num_envs, obstacles=rows, waves=waves, random_boat=random_boat,
                                 random_goal=random_goal, continuous=self.continuous, device=device, seed=seed,
-                                auto_reset=self.num_envs > 1)
+                                auto_reset=autoreset if self.num_envs > 1 else False)
         self._needs_reset = True
 
     # ------------------------------------------------------------------ reference-shaped API

@@ -262,13 +262,14 @@ def test_reset_fixed_pose_and_distribution(torch):
 # ------------------------------------------------------------------------------------------------
 # rollouts: per-step launches == fused launch == graph replay
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [1, 2], ids=["same_step", "next_step"])
 @pytest.mark.parametrize("continuous", [False, True])
-def test_fused_rollout_equals_stepwise(torch, continuous):
+def test_fused_rollout_equals_stepwise(torch, continuous, mode):
     from aquaticgymenv_amd import presets
-    n, T = 20000, 64
+    n, T = 20000 + 13, 64
     outs = []
     for fused in (False, True):
-        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=31, auto_reset=True)
+        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=31, auto_reset=mode)
         env.reset()
         if continuous:
             g = torch.Generator(device="cuda").manual_seed(3)
@@ -285,12 +286,13 @@ def test_fused_rollout_equals_stepwise(torch, continuous):
     assert (outs[0][3] != 0).sum() > 0
 
 
-def test_graph_replay_equals_eager(torch):
+@pytest.mark.parametrize("reset_mode", [1, 2], ids=["same_step", "next_step"])
+def test_graph_replay_equals_eager(torch, reset_mode):
     from aquaticgymenv_amd import presets
     n, T = 30000, 16
     res = []
     for mode in ("eager", "graph"):
-        env = _make(torch, n, presets.BENCH8, seed=8, auto_reset=True)
+        env = _make(torch, n, presets.BENCH8, seed=8, auto_reset=reset_mode)
         env.reset()
         if mode == "eager":
             for _ in range(3):
@@ -338,14 +340,14 @@ def test_shard_invariance(torch):
     """range-partitioned shards (env_offset) reproduce the single-device batch bit for bit."""
     from aquaticgymenv_amd import presets
     n, parts, T = 16384, 4, 12
-    whole = _make(torch, n, presets.BENCH8, seed=2024, auto_reset=True)
+    whole = _make(torch, n, presets.BENCH8, seed=2024, auto_reset=2)
     whole.reset()
     whole.rollout(T, keep_all=False)
     torch.cuda.synchronize()
     ref = whole.state[:, :n].cpu().numpy()
     per = n // parts
     for p in range(parts):
-        shard = _make(torch, per, presets.BENCH8, seed=2024, auto_reset=True, env_offset=p * per)
+        shard = _make(torch, per, presets.BENCH8, seed=2024, auto_reset=2, env_offset=p * per)
         shard.reset()
         shard.rollout(T, keep_all=False)
         torch.cuda.synchronize()

@@ -14,7 +14,7 @@ for f in glob.glob(d + "/stats/**/*kernel_stats.csv", recursive=True):
         name = r["Name"]
         short = name[:90]
         print("%-92s calls %6s avg %10.1f ns  min %8s max %8s  %6s%%" % (short, r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
-        if "step_kernel" in name:
+        if "::step_" in name:
             out["step_kernel_avg_ns"] = float(r["AverageNs"])
             out["step_kernel_calls"] = int(r["Calls"])
             out["step_kernel_name"] = name
@@ -22,7 +22,7 @@ for key in ("fetch", "write"):
     acc, cnt = collections.defaultdict(float), collections.Counter()
     for f in glob.glob(d + "/%s/**/*counter_collection.csv" % key, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"]:
+            if "::step_" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[r["Counter_Name"]] += 1
     for k in acc:
