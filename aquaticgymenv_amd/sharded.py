@@ -50,9 +50,17 @@ class DoneMaskExchange(object):
                          for _ in range(nbuf)]
         self._slot = 0
         self._pending = [None] * nbuf
+        self._source_busy = {}            # source_id -> event after which the caller may overwrite that source
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
-    def gather_async(self, local_bits):
+    def wait_source(self, source_id):
+        """Make the current stream wait until the gather that last READ the caller's buffer `source_id` is done
+        (call before the kernels that overwrite that buffer)."""
+        ev = self._source_busy.pop(source_id, None)
+        if ev is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def gather_async(self, local_bits, source_id=None):
         """Queue the all-gather of local_bits ([steps][words] int64, contiguous).  Returns the slot index
         whose `gathered[slot]` holds the result after wait(slot)."""
         torch, dist = self.torch, self.dist
@@ -70,6 +78,8 @@ class DoneMaskExchange(object):
                     out[0].copy_(local_bits, non_blocking=True)
                     local_bits.record_stream(self._side)
                 self._pending[slot] = self._side.record_event()
+                if source_id is not None:
+                    self._source_busy[source_id] = self._pending[slot]
             else:
                 out[0].copy_(local_bits)
             return slot
@@ -79,6 +89,8 @@ class DoneMaskExchange(object):
                 dist.all_gather_into_tensor(out.view(-1), local_bits.view(-1), group=self.group)
                 local_bits.record_stream(self._side)
             self._pending[slot] = self._side.record_event()
+            if source_id is not None:
+                self._source_busy[source_id] = self._pending[slot]
         else:
             dist.all_gather_into_tensor(out.view(-1), local_bits.view(-1), group=self.group)
         return slot

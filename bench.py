@@ -28,7 +28,8 @@ if ROOT not in sys.path:
 A_DISCRETE = 62      # algorithmic bytes per world-step, SURVEY.md 8(d): 33 read + 29 written
 A_CONTINUOUS = 69
 HBM_PEAK_GBPS = 8000.0
-CHUNK = 100
+CHUNK = 100          # steps per captured HIP graph
+GATHER_EVERY = 5     # graphs per done-mask all-gather (N > 1): one [500][words] block per exchange
 
 
 def parse():
@@ -46,20 +47,30 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
     ap.add_argument("--vec", type=int, default=0, help="worlds per lane (0 = auto)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the done-mask exchange (side stream, double buffer) even on one GPU: rehearsal of the N > 1 path")
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel and a 16M-world point")
     return ap.parse_args()
 
 
-def run_steps(env, graph, actions, n_steps, exchange, hist):
-    """exactly n_steps batched steps; done masks of full chunks are all-gathered on the side stream."""
+def run_steps(env, graphs, actions, n_steps, exchange, hist, state):
+    """exactly n_steps batched steps.  Full chunks replay captured graphs; every GATHER_EVERY chunks the
+    [GATHER_EVERY * CHUNK][words] block of done masks they wrote is all-gathered on the side stream
+    (double-buffered: the step stream only waits for the gather that last read the buffer it is about to
+    overwrite, i.e. the one queued two blocks ago)."""
     full, rem = divmod(n_steps, CHUNK)
-    for c in range(full):
-        if graph is not None:
-            graph[c & 1].launch()
+    for _ in range(full):
+        c = state["chunk"]
+        buf, w = (c // GATHER_EVERY) & 1, c % GATHER_EVERY
+        if exchange is not None and w == 0:
+            exchange.wait_source(buf)
+        if graphs is not None:
+            graphs[buf][w].launch()
         else:
-            env.rollout(CHUNK, actions=actions, keep_all=False, done_history=hist[c & 1])
-        if exchange is not None:
-            exchange.gather_async(hist[c & 1])
+            env.rollout(CHUNK, actions=actions, keep_all=False, done_history=hist[buf][w * CHUNK:(w + 1) * CHUNK])
+        if exchange is not None and w == GATHER_EVERY - 1:
+            exchange.gather_async(hist[buf], source_id=buf)
+        state["chunk"] = c + 1
     if rem:
         env.rollout(rem, actions=actions, keep_all=False)
 
@@ -126,13 +137,16 @@ def main():
     else:
         actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=gen, dtype=torch.int64).to(torch.uint8)
     words = env.ld // 64
-    hist = [torch.zeros((CHUNK, words), dtype=torch.int64, device=dev) for _ in range(2)]
-    exchange = DoneMaskExchange(CHUNK, words, dev) if world > 1 else None
+    hist = [torch.zeros((GATHER_EVERY * CHUNK, words), dtype=torch.int64, device=dev) for _ in range(2)]
+    exchange = DoneMaskExchange(GATHER_EVERY * CHUNK, words, dev) if (world > 1 or args.force_exchange) else None
     graph = None
     if not args.eager:
-        graph = [env.capture_rollout(CHUNK, actions=actions, keep_all=False, done_history=hist[i]) for i in range(2)]
+        graph = [[env.capture_rollout(CHUNK, actions=actions, keep_all=False,
+                                      done_history=hist[b][w * CHUNK:(w + 1) * CHUNK]) for w in range(GATHER_EVERY)]
+                 for b in range(2)]
+    progress = {"chunk": 0}
 
-    run_steps(env, graph, actions, args.warmup, exchange, hist)
+    run_steps(env, graph, actions, args.warmup, exchange, hist, progress)
     if exchange is not None:
         exchange.finish()
     torch.cuda.synchronize()
@@ -142,7 +156,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    run_steps(env, graph, actions, args.steps, exchange, hist)
+    run_steps(env, graph, actions, args.steps, exchange, hist, progress)
     e1.record()
     if exchange is not None:
         exchange.finish()
@@ -158,7 +172,7 @@ def main():
         wall = float(tmax.item())
 
     # sanity on the timed work: worlds did move and episodes did end (no cached / skipped work)
-    ended = int((hist[0].cpu().numpy().view(np.uint64) != 0).sum())
+    ended = int((hist[0][:CHUNK].cpu().numpy().view(np.uint64) != 0).sum())
     assert env._tick >= args.steps + args.warmup and (ended > 0 or args.no_auto_reset)
 
     result = None

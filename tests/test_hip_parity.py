@@ -380,6 +380,29 @@ def test_obs_is_a_view_and_invariants_at_full_size(torch):
     assert torch.equal(env.state, env2.state) and torch.equal(env.time, env2.time)
 
 
+def test_done_mask_exchange_on_device(torch):
+    """the N > 1 plumbing on one GPU (world size 1): side stream, event ordering, double buffer; the gathered
+    block equals the ballot words the kernels wrote and those equal term != 0."""
+    from aquaticgymenv_amd import presets
+    from aquaticgymenv_amd.sharded import DoneMaskExchange, unpack_done_words
+    n, T = 10000, 20
+    env = _make(torch, n, presets.BENCH8, seed=12, auto_reset=2)
+    env.reset()
+    words = env.ld // 64
+    ex = DoneMaskExchange(T, words, env.device)
+    hist = [torch.zeros((T, words), dtype=torch.int64, device=env.device) for _ in range(2)]
+    for c in range(4):
+        reward, term = env.rollout(T, keep_all=True, done_history=hist[c & 1])
+        slot = ex.gather_async(hist[c & 1])
+        ex.wait(slot)
+        torch.cuda.synchronize()
+        g = ex.gathered[slot][0].cpu().numpy()
+        t = term[:, :n].cpu().numpy()
+        for s in range(T):
+            assert np.array_equal(unpack_done_words(g[s], n), (t[s] != 0).astype(np.uint8))
+    ex.finish()
+
+
 # ------------------------------------------------------------------------------------------------
 # the Gym-shaped facade
 # ------------------------------------------------------------------------------------------------
