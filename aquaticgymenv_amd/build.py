@@ -61,8 +61,6 @@ def build_variant(name, flags, verbose=False):
 if __name__ == "__main__":
     if "--variants" in sys.argv:
         for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("lds", ["-DAQUA_OBST_LDS=1"]),
-                            ("group4", ["-DAQUA_RESET_GROUP=4"]), ("group16", ["-DAQUA_RESET_GROUP=16"]),
-                            ("stamps", ["-DAQUA_STAMPS=1"]), ("stamps_u4", ["-DAQUA_STAMPS=1", "-DAQUA_RESEED_UNROLL=4"]), ("stamps_u8", ["-DAQUA_STAMPS=1", "-DAQUA_RESEED_UNROLL=8"]),
-                            ("u4", ["-DAQUA_RESEED_UNROLL=4"]), ("u8", ["-DAQUA_RESEED_UNROLL=8"])):
+                            ("stamps", ["-DAQUA_STAMPS=1"]), ("noprio", ["-DAQUA_WORKER_PRIO=0"])):
             print(build_variant(name, flags, verbose=True))
     print(build_hip(force="--force" in sys.argv, verbose=True))
