@@ -15,7 +15,8 @@
 
 namespace aqua {
 
-constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band, in world units
+constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band of the plain float32 margins, in world units
+constexpr float BAND_TIGHT = 4.0e-6f;    // ... of the error-compensated margins (second look, see fast_step)
 constexpr int RESET_TRIES = 64;
 constexpr int MAX_OBST = 64;
 
@@ -34,7 +35,8 @@ struct ObstHeader {
     int32_t n_obstacles, n_circles;
     float band2;                // knife-edge band for the SQUARED margin d^2 - R^2: 2.5 * R_max * BAND
     float r_max;
-    int32_t reserved[4];
+    float band2_tight;          // the same for the compensated margins: 2.5 R_max BAND_TIGHT + 4 ulp(R_max^2)
+    int32_t reserved[3];
 };
 static_assert(sizeof(ObstHeader) == 32, "ObstHeader");
 
@@ -62,7 +64,7 @@ struct StepConst {              // wave-uniform
     int waves;
     int time_limit;             // aqua.py:91
     int K, Kc;                  // obstacles, of which the first Kc are circles
-    float band2;
+    float band2, band2_tight;
     ObstPtr obst;               // float32 table (scalar-loaded from the blob, or the LDS copy)
     const double* obst64;       // global float64 rows [K][5] (exact path)
 };
@@ -369,8 +371,33 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float num = fmaf(ddx, ex + fx, ddy * (ey + fy));
     const float shaped = dsum > 0.0f ? 0.7f * (num * __builtin_amdgcn_rcpf(dsum)) : 0.0f;
 
-    const bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
-    term = (fminf(mc, mo) < 0.0f) ? 1u : (tn > k.time_limit ? 2u : (mg <= 0.0f ? 3u : 0u));   // aqua.py:200-211
+    bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
+    float mc_f = mc, mo_f = mo, mg_f = mg;
+    if (__any(knife)) {
+        // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
+        // by the rounding of x' = x + ddx itself (up to 3.8e-6).  Carry the rounding error of that sum
+        // (xlo = ddx - (x' - x), exact: FastTwoSum) through the three margins; what is left is the error of
+        // ddx (~2.5e-7) and of d^2 (~4 ulp of R^2), so the band shrinks from 1e-4 to 4e-6 and the float64
+        // path -- whose length is added to the launch whenever ANY wavefront takes it -- is entered
+        // ~25 times less often.
+        const float xlo = ddx - (xn - e.x), ylo = ddy - (yn - e.y);
+        const float mb2 = fminf(fminf((xn - 2.5f) + xlo, (yn - 2.5f) + ylo), fminf((97.5f - xn) - xlo, (97.5f - yn) - ylo));
+        float mo2 = 3.0e38f;
+        for (int j = 0; j < k.Kc; ++j) {
+            const float dx = (xn - k.obst[j].cx) + xlo, dy = (yn - k.obst[j].cy) + ylo;
+            mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
+        }
+        for (int j = k.Kc; j < k.K; ++j) {
+            const float dx = fmaxf(fabsf((xn - k.obst[j].cx) + xlo) - k.obst[j].hx, 0.0f);
+            const float dy = fmaxf(fabsf((yn - k.obst[j].cy) + ylo) - k.obst[j].hy, 0.0f);
+            mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
+        }
+        const float gx2 = (e.gx - xn) - xlo, gy2 = (e.gy - yn) - ylo;
+        const float mg2 = __builtin_amdgcn_sqrtf(fmaf(gx2, gx2, gy2 * gy2)) - 5.0f;
+        if (knife) { mc_f = mb2; mo_f = mo2; mg_f = mg2; }
+        knife = knife && ((fminf(fabsf(mb2), fabsf(mg2)) < BAND_TIGHT) || (fabsf(mo2) < k.band2_tight));
+    }
+    term = (fminf(mc_f, mo_f) < 0.0f) ? 1u : (tn > k.time_limit ? 2u : (mg_f <= 0.0f ? 3u : 0u));   // aqua.py:200-211
     reward = term == 0u ? shaped : (term == 3u ? 10.0f : -10.0f);
     e.x = xn; e.y = yn; e.th = thn; e.wx = wxn; e.wy = wyn; e.t = tn;
     return knife;

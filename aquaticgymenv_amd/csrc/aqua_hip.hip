@@ -148,12 +148,13 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K;
     k.obst = obst;
-    k.Kc = 0; k.band2 = 0.0f;
+    k.Kc = 0; k.band2 = 0.0f; k.band2_tight = 0.0f;
     if (a.K > 0) {                       // header fields: uniform scalar loads
         const ObstHeader __attribute__((address_space(4)))* h =
             (const ObstHeader __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
         k.Kc = h->n_circles;
         k.band2 = h->band2;
+        k.band2_tight = h->band2_tight;
     }
     k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstHeader) +
                                                sizeof(ObstF) * a.K);
@@ -956,6 +957,8 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
     h->n_circles = n_circles;
     h->r_max = static_cast<float>(r_max);
     h->band2 = static_cast<float>(2.5 * (r_max + static_cast<double>(BAND)) * static_cast<double>(BAND));
+    h->band2_tight = static_cast<float>(2.5 * (r_max + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) +
+                                        4.0 * 1.1920929e-7 * r_max * r_max);
     return 0;
 }
 
