@@ -16,7 +16,10 @@
 namespace aqua {
 
 constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band of the plain float32 margins, in world units
-constexpr float BAND_TIGHT = 4.0e-6f;    // ... of the error-compensated margins (second look, see fast_step)
+#ifndef AQUA_BAND_TIGHT
+#define AQUA_BAND_TIGHT 4.0e-6f
+#endif
+constexpr float BAND_TIGHT = AQUA_BAND_TIGHT;    // ... of the error-compensated margins (second look, see fast_step)
 constexpr int RESET_TRIES = 64;
 constexpr int MAX_OBST = 64;
 

@@ -527,7 +527,10 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
 // re-seed the tile's pending worlds.  Main wavefronts load `time` first, append their pending worlds to
 // the LDS list, signal arrival (LDS counter, no barrier) and carry on; the workers wait for the last
 // arrival only.
-constexpr int NS_MAIN_WAVES = 6, NS_WORK_WAVES = 2;
+#ifndef AQUA_NS_MAIN_WAVES
+#define AQUA_NS_MAIN_WAVES 6
+#endif
+constexpr int NS_MAIN_WAVES = AQUA_NS_MAIN_WAVES, NS_WORK_WAVES = 2;
 constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = (NS_MAIN_WAVES + NS_WORK_WAVES) * 64;
 
 struct NsShared {
@@ -558,12 +561,14 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 #if AQUA_WORKER_PRIO
         __builtin_amdgcn_s_setprio(3);      // the worker's chain is the longest in the workgroup: let it issue first
 #endif
+        AQUA_RTSTAMP(0);
         uint32_t spins = 0;
         while (__hip_atomic_load(&sh.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
                    static_cast<uint32_t>(NS_MAIN_WAVES) && spins < (1u << 22)) {
             __builtin_amdgcn_s_sleep(1);
             ++spins;
         }
+        AQUA_RTSTAMP(1);
         const uint32_t n_pending = sh.count;
         constexpr uint32_t GROUPS = NS_WORK_WAVES * (64 / RESET_GROUP);
         for (uint32_t qb = (wave - NS_MAIN_WAVES) * (64 / RESET_GROUP); qb < n_pending; qb += GROUPS) {
@@ -579,10 +584,12 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
                 trow[i] = e.t;
             }
         }
+        AQUA_RTSTAMP(2);
         return;
     }
 
     // ---- main wavefront
+    AQUA_RTSTAMP(0);
     const uint32_t off = threadIdx.x;                  // < NS_TILE
     const bool valid = static_cast<int64_t>(off) < rem;
     int32_t t0 = valid ? trow[off] : 0;
@@ -615,6 +622,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     float rew;
     uint32_t code;
     const bool live = valid && !pending;
+    AQUA_RTSTAMP(1);
     const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
     if (__any(knife)) {
         if (knife) {
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         row0[5 * ld + off] = e.wx; row0[6 * ld + off] = e.wy;
         trow[off] = done ? -1 : e.t;
     }
+    AQUA_RTSTAMP(2);
 }
 
 // ------------------------------------------------------------------ T steps in one launch
@@ -1000,7 +1009,22 @@ __global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, i
         }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
     }
-    if (threadIdx.x == 0) { out[0] = (t1 - t0) / iters; out[1] = (t2 - t1) / iters; }
+    // exact path: first (cold instruction cache) call vs later calls, one wavefront
+    unsigned long long e0, e1, e2, e3;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0)::"memory");
+    ExactOut o = exact_step(50.0f + acc * 0.0f, 50.0f, 0.3f, 20.0f, 80.0f, 0.01f, 0.02f, 5, exact_motion_discrete(threadIdx.x % 3), k.K,
+                            k.obst64, k.obst, k.band2, k.time_limit);
+    acc += o.x;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory");
+    o = exact_step(51.0f + acc * 0.0f, 50.0f, 0.3f, 20.0f, 80.0f, 0.01f, 0.02f, 5, exact_motion_discrete(threadIdx.x % 3), k.K, k.obst64,
+                   k.obst, k.band2, k.time_limit);
+    acc += o.x;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e2)::"memory");
+    o = exact_step(52.0f + acc * 0.0f, 50.0f, 0.3f, 20.0f, 80.0f, 0.01f, 0.02f, 5, exact_motion_discrete(threadIdx.x % 3), k.K, k.obst64,
+                   k.obst, k.band2, k.time_limit);
+    acc += o.x;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e3)::"memory");
+    if (threadIdx.x == 0) { out[0] = (t1 - t0) / iters; out[1] = (t2 - t1) / iters; out[3] = e1 - e0; out[4] = e2 - e1; out[5] = e3 - e2; }
     if (acc == 12345.678f) out[2] = 1;
 }
 

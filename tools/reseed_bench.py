@@ -8,10 +8,11 @@ from aquaticgymenv_amd import _capi, presets
 for name, rows in (("bench8", presets.BENCH8), ("none", presets.NONE)):
     blob = _capi.pack_obstacles(rows)
     dev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda() if blob else None
-    out = torch.zeros(4, dtype=torch.int64, device="cuda")
+    out = torch.zeros(8, dtype=torch.int64, device="cuda")
     p = _capi.AquaParams(waves=1, random_boat=1, random_goal=1, time_limit=1000)
     f = _capi.lib.aqua_debug_reseed_bench
     f.argtypes = [ctypes.POINTER(_capi.AquaParams), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     _capi.check(f(ctypes.byref(p), dev.data_ptr() if dev is not None else None, rows.shape[0], out.data_ptr(), None), "bench")
     torch.cuda.synchronize()
-    print(name, "reset_env_group: %d cycles/call   philox draw: %d cycles" % (int(out[0]), int(out[1])))
+    print(name, "reset_env_group: %d cycles/call   philox draw: %d cycles   exact_step 1st/2nd/3rd call: %d / %d / %d cycles" %
+          (int(out[0]), int(out[1]), int(out[3]), int(out[4]), int(out[5])))

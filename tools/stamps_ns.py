@@ -9,8 +9,9 @@ from aquaticgymenv_amd.batched import BatchedAqua
 n = 262144
 env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=2, device="cuda:0")
 env.reset()
-blocks = (n + 383) // 384
-stamps = torch.zeros((blocks * 8, 8), dtype=torch.int64, device="cuda")
+MW = int(os.environ.get('NS_MAIN', '8'))
+blocks = (n + 64 * MW - 1) // (64 * MW)
+stamps = torch.zeros((blocks * (MW + 2), 8), dtype=torch.int64, device="cuda")
 _capi.lib.aqua_debug_set_stamps.argtypes = [ctypes.c_void_p]
 _capi.check(_capi.lib.aqua_debug_set_stamps(stamps.data_ptr()), "set stamps")
 acts = torch.randint(0, 3, (64, env.ld), device="cuda", dtype=torch.int64).to(torch.uint8)
@@ -19,9 +20,9 @@ for rep in range(5):
     stamps.zero_()
     env.rollout(1, actions=acts, keep_all=False)
     torch.cuda.synchronize()
-s = stamps.cpu().numpy().astype(np.float64).reshape(blocks, 8, 8)
+s = stamps.cpu().numpy().astype(np.float64).reshape(blocks, MW + 2, 8)
 t0 = s[:, :, 0][s[:, :, 0] > 0].min()
-main, work = s[:, :6, :], s[:, 6:, :]
+main, work = s[:, :MW, :], s[:, MW:, :]
 def us(x): return x * 1e-2
 print("kernel span (first start -> last end): %.2f us" % us(max(main[:, :, 2].max(), work[:, :, 2].max()) - t0))
 print("main  : start %5.2f..%5.2f  loads+philox done median +%.2f  end median +%.2f  p99 +%.2f  max +%.2f  (latest end at %.2f)" % (
