@@ -190,13 +190,23 @@ class BatchedAqua(object):
         self._tick += 1
         return self.obs
 
-    def step(self, action=None, soa=False, noise=None, sample_actions=False):
+    def _device_policy(self, name):
+        if name in (True, "random"):
+            return _capi.ACT_SAMPLE_C if self.continuous else _capi.ACT_SAMPLE_D
+        if name == "bearing":
+            if self.continuous:
+                raise ValueError("the bearing policy (main/testing/test_optimal.py) is defined for discrete actions")
+            return _capi.ACT_BEARING
+        raise ValueError("unknown on-device policy %r (use 'random' or 'bearing')" % (name,))
+
+    def step(self, action=None, soa=False, noise=None, sample_actions=False, policy=None):
         """One batched step (aqua.py:135-213).  Returns (obs view [N,5], reward [N], term [N] uint8).
-        noise: optional float32 [2][>=N] uniforms in [-1, 1) replacing the Philox draws (parity tests)."""
+        noise: optional float32 [2][>=N] uniforms in [-1, 1) replacing the Philox draws (parity tests).
+        policy: 'random' (== sample_actions) or 'bearing': the action is produced on the device."""
         torch = self.torch
         n = self.num_envs
-        if sample_actions:
-            keep, aptr, kind, ald = None, None, (_capi.ACT_SAMPLE_C if self.continuous else _capi.ACT_SAMPLE_D), 0
+        if sample_actions or policy is not None:
+            keep, aptr, kind, ald = None, None, self._device_policy(policy or "random"), 0
         else:
             keep, aptr, kind, ald = self._as_action(action, soa)
         nptr, nld = None, 0
@@ -218,8 +228,8 @@ class BatchedAqua(object):
     def _rollout_args(self, steps, actions, soa_ld):
         torch = self.torch
         n = self.num_envs
-        if actions is None:
-            return None, (_capi.ACT_SAMPLE_C if self.continuous else _capi.ACT_SAMPLE_D), 0, 0
+        if actions is None or isinstance(actions, str):
+            return None, self._device_policy(actions or "random"), 0, 0
         if self.continuous:
             if actions.dtype != torch.float32 or actions.dim() != 3 or actions.shape[0] < steps or actions.shape[1] != 2 \
                     or actions.shape[2] < n or actions.stride(2) != 1:
@@ -254,7 +264,8 @@ class BatchedAqua(object):
 
     def rollout(self, steps, actions=None, fused=False, keep_all=True, done_history=None):
         """`steps` consecutive batched steps queued from C without returning to Python.
-        actions: None -> uniform random actions sampled on the device from the step's Philox draw;
+        actions: None / 'random' -> uniform random actions sampled on the device; 'bearing' -> the bearing policy
+                 of main/testing/test_optimal.py evaluated on the device;
                  discrete: uint8/int32/int64 [T][>=N]; continuous: float32 [T][2][>=N].
         fused=True runs them as ONE launch with the state held in registers.
         Returns (reward, term): [T][ld] tensors when keep_all, else the last step's [ld] buffers."""

@@ -93,8 +93,11 @@ template <bool SCALAR_KEY = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
                                                uint32_t c3, uint32_t (&out)[4])
 {
+#ifndef AQUA_PHILOX_ROUNDS
+#define AQUA_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < AQUA_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 product per half round (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32:
         // integer multiplies issue at a quarter of the VALU rate and are the bulk of this routine
         const uint64_t p0 = static_cast<uint64_t>(c0) * 0xD2511F53ull;
@@ -155,6 +158,22 @@ __device__ __forceinline__ float wrap_add(float th, float w)
     const float turns = s >= PI_F ? -1.0f : (s <= -PI_F ? 1.0f : 0.0f);
     s = fmaf(turns, TWO_PI_HI, s);           // exact (Sterbenz range), then the low part of 2 pi
     return fmaf(turns, TWO_PI_LO, s);
+}
+
+// The hand-coded bearing policy of main/testing/test_optimal.py:8-28: turn towards the goal while the
+// bearing error exceeds 8 degrees, else full throttle.  Like the reference it does NOT wrap the difference of
+// the two [0, 2 pi) angles.  float32; worlds within ~1e-6 rad of the threshold may pick the other action
+// than a float64 evaluation would.
+__device__ __forceinline__ int bearing_action(float x, float y, float th, float gx, float gy)
+{
+    constexpr float TWO_PI = 6.28318530717958647692f, HALF_PI = 1.57079632679489661923f;
+    constexpr float THRESHOLD = 0.13962634015954636f;          // 8 / 180 * pi
+    float boat = (th + HALF_PI) + TWO_PI;                       // in [pi/2 + pi, 7 pi / 2): one conditional subtraction
+    boat = boat >= TWO_PI ? boat - TWO_PI : boat;               // == (theta + pi/2 + 2 pi) % (2 pi)
+    float goal = atan2f(gy - y, gx - x);
+    goal = goal < 0.0f ? goal + TWO_PI : goal;                  // == (atan2 + 2 pi) % (2 pi)
+    const float diff = goal - boat;
+    return fabsf(diff) > THRESHOLD ? (diff > 0.0f ? 0 : 1) : 2;
 }
 
 // continuous thrusts -> (h, w, chord) (aqua.py:159-170 with r eliminated: chord = 2 r sin(w/2) = v sinc(w/2))

@@ -386,6 +386,10 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         }
     }
 
+    if constexpr (AK == AQUA_ACT_BEARING) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) aidx[j] = bearing_action(x[j], y[j], th[j], gx[j], gy[j]);
+    }
     AQUA_STAMP(1);          // Philox done (loads may still be in flight)
     float rew[VEC];
     uint8_t code[VEC];
@@ -616,6 +620,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
         else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
     }
+    if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
     EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
     const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
@@ -718,6 +723,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
                 if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(w0[0]);
                 else { vl = sample_thrust(w0[0]); vr = sample_thrust(w1[0]); }
             }
+            if constexpr (AK == AQUA_ACT_BEARING) idx = bearing_action(e.x, e.y, e.th, e.gx, e.gy);
             const Motion m = decode_motion<AK>(k, idx, vl, vr);
             const EnvState before = e;
             EnvState after = e;
@@ -866,6 +872,7 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
         case AQUA_ACT_F32X2: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
         case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
         case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
+        case AQUA_ACT_BEARING: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_BEARING>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -883,6 +890,7 @@ hipError_t launch_step_ns(const StepArgs& a, int kind, hipStream_t s)
         case AQUA_ACT_F32X2: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
         case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
         case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
+        case AQUA_ACT_BEARING: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_BEARING>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -899,7 +907,7 @@ hipError_t launch_step_any(const StepArgs& a, int kind, int vec, hipStream_t s)
 int check_step_buffers(int64_t N, const void* action, int action_kind, int64_t action_ld, const float* noise,
                        int64_t noise_ld, const float* reward, const uint8_t* term)
 {
-    if (action_kind < AQUA_ACT_U8 || action_kind > AQUA_ACT_SAMPLE_C)
+    if (action_kind < AQUA_ACT_U8 || action_kind > AQUA_ACT_BEARING)
         return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
     if (N > 0 && action_kind <= AQUA_ACT_F32X2 && action == nullptr) return fail(AQUA_E_INVALID, "action is NULL");
     if (action_kind == AQUA_ACT_F32X2 && action_ld < N) return fail(AQUA_E_INVALID, "action_ld < N");
@@ -1140,6 +1148,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
         case AQUA_ACT_F32X2: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
         case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
         case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
+        case AQUA_ACT_BEARING: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_BEARING>), grid, block, 0, s, a); break;
         default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
     }
     const hipError_t e = hipGetLastError();

@@ -47,8 +47,10 @@ extern "C" {
 #define AQUA_ACT_I32       1    /* int32[N]   discrete; -3..-1 wrap like a Python list index */
 #define AQUA_ACT_I64       2    /* int64[N]   discrete */
 #define AQUA_ACT_F32X2     3    /* float32 [2][action_ld]: row 0 vL, row 1 vR (continuous, clipped to [0.2, 0.5]) */
-#define AQUA_ACT_SAMPLE_D  4    /* no buffer: uniform discrete action from the step's Philox draw (word 2) */
-#define AQUA_ACT_SAMPLE_C  5    /* no buffer: vL, vR ~ U[0.2, 0.5) from the step's Philox draw (words 2, 3) */
+#define AQUA_ACT_SAMPLE_D  4    /* no buffer: uniform discrete action from Philox stream 4 */
+#define AQUA_ACT_SAMPLE_C  5    /* no buffer: vL, vR ~ U[0.2, 0.5) from Philox stream 4 */
+#define AQUA_ACT_BEARING   6    /* no buffer: the hand-coded bearing policy of main/testing/test_optimal.py:8-28,
+                                   evaluated on the device from the world's own observation (discrete action) */
 
 /* termination codes written to `term` (aqua.py:194-211, exactly one info flag is True when done) */
 #define AQUA_TERM_NONE     0

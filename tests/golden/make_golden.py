@@ -430,6 +430,48 @@ def gen_resets(mod):
     return out
 
 
+def bearing_action(state):
+    """the hand-coded bearing policy of main/testing/test_optimal.py:8-28, restated (that script imports
+    TensorFlow through impl.utils and cannot be loaded here): turn towards the goal while the bearing error
+    exceeds 8 degrees, else full throttle.  Note the reference does not wrap the angle difference."""
+    two_pi = 2 * np.pi
+    boat_angle = (state[2] + np.pi / 2 + two_pi) % two_pi
+    goal_angle = (np.arctan2(state[4] - state[1], state[3] - state[0]) + two_pi) % two_pi
+    diff = goal_angle - boat_angle
+    if 8 / 180 * np.pi < abs(diff):
+        return 0 if diff > 0 else 1
+    return 2
+
+
+def gen_policy_stats(mod):
+    """episodes of the reference env driven by the bearing policy: behavioural target for the batched build
+    (rollout loop of main/testing/__init__.py:17-36)."""
+    out = {}
+    for ci in (0, 1):
+        env = make_env(mod, CONFIGS[ci])
+        np.random.seed(4242 + ci)
+        n_ep = 1500
+        codes, steps, rewards = [], [], []
+        for _ in range(n_ep):
+            state = env.reset()
+            total = 0.0
+            for step in range(1, 1200):
+                state, r, done, info = env.step(bearing_action(state))
+                total += r
+                if done:
+                    break
+            codes.append(1 if info["Termination.collided"] else 2 if info["Termination.time"] else 3)
+            steps.append(step)
+            rewards.append(total)
+        out["policy_cfg%d_term" % ci] = np.asarray(codes, dtype=np.int32)
+        out["policy_cfg%d_steps" % ci] = np.asarray(steps, dtype=np.int32)
+        out["policy_cfg%d_reward" % ci] = np.asarray(rewards, dtype=np.float64)
+        print("bearing policy, %s: success %.3f collided %.3f time %.3f mean steps %.1f mean reward %.2f" % (
+            CONFIGS[ci][0], np.mean(np.asarray(codes) == 3), np.mean(np.asarray(codes) == 1), np.mean(np.asarray(codes) == 2),
+            np.mean(steps), np.mean(rewards)))
+    return out
+
+
 def time_reference(mod):
     print("reference step() timing in this container (1 core, random actions, reset on done)")
     for ci in (0, 3, 4):
@@ -471,6 +513,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "step_golden.npz"), **cols)
     np.savez_compressed(os.path.join(HERE, "traj_golden.npz"), **gen_trajectories(mod, rng))
     np.savez_compressed(os.path.join(HERE, "reset_golden.npz"), **gen_resets(mod))
+    np.savez_compressed(os.path.join(HERE, "policy_golden.npz"), **gen_policy_stats(mod))
     terms = np.bincount(cols["term"], minlength=4)
     print("rows", len(rows), "hand", n_hand, "term histogram", terms.tolist())
     band = (np.abs(cols["m_border"]) < 1e-4) | (np.abs(cols["m_obst"]) < 1e-4) | (np.abs(cols["m_goal"]) < 1e-4)
