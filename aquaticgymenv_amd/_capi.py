@@ -48,10 +48,10 @@ def _load():
     lib.aqua_obstacle_blob_bytes.restype = ctypes.c_size_t
     lib.aqua_pack_obstacles.argtypes = [vp, ci, vp, ctypes.c_size_t]
     lib.aqua_step_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, vp, ci, i64, vp, i64, u64, u64, vp, vp, vp, vp,
-                                  ci, vp]
+                                  vp, ci, vp]
     lib.aqua_reset_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_rollout_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp, vp, vp,
-                                     i64, vp, i64, ci, vp]
+                                     i64, vp, i64, vp, ci, vp]
     lib.aqua_rollout_fused_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp,
                                            vp, vp, i64, ci, vp]
     lib.aqua_tick_advance.argtypes = [vp, u64, vp]

@@ -59,7 +59,7 @@ class BatchedAqua(object):
     """
 
     def __init__(self, num_envs, obstacles=False, waves=True, random_boat=True, random_goal=True, continuous=False,
-                 device=None, seed=None, env_offset=0, auto_reset=True):
+                 device=None, seed=None, env_offset=0, auto_reset=True, normalized_obs=False):
         import torch
         self.torch = torch
         if num_envs < 1:
@@ -103,6 +103,8 @@ class BatchedAqua(object):
             else:
                 self._blob = None
             self._tick_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            # optional fused epilogue (main/impl/utils.py:15-33): obs / (high - low), angle + 0.5
+            self.obs_norm_buf = torch.zeros((5, self.ld), dtype=torch.float32, device=dev) if normalized_obs else None
         self._tick = 0
         self._device_tick = 0
         self._action_soa = None           # staging for (N, 2) -> [2][ld] continuous actions
@@ -123,6 +125,16 @@ class BatchedAqua(object):
     def obs(self):
         """[N, 5] view (x, y, theta, goal_x, goal_y) of the state rows -- no copy (aqua.py:213)."""
         return self.state[:5, :self.num_envs].t()
+
+    @property
+    def obs_norm(self):
+        """[N, 5] view of the normalised observation written by the step kernels (normalized_obs=True)."""
+        if self.obs_norm_buf is None:
+            raise RuntimeError("construct with normalized_obs=True")
+        return self.obs_norm_buf[:, :self.num_envs].t()
+
+    def _norm_ptr(self):
+        return self.obs_norm_buf.data_ptr() if self.obs_norm_buf is not None else None
 
     @property
     def wave(self):
@@ -219,8 +231,8 @@ class BatchedAqua(object):
             _capi.check(_capi.lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
                                                 self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald,
                                                 nptr, nld, self.seed, self._tick, None, self.reward.data_ptr(),
-                                                self.term.data_ptr(), self.done_bits.data_ptr(), int(self.auto_reset),
-                                                self._stream()), "aqua_step_f32")
+                                                self.term.data_ptr(), self.done_bits.data_ptr(), self._norm_ptr(),
+                                                int(self.auto_reset), self._stream()), "aqua_step_f32")
         self._tick += 1
         del keep
         return self.obs, self.reward[:n], self.term[:n]
@@ -286,7 +298,8 @@ class BatchedAqua(object):
                                                  self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
                                                  steps, aptr, kind, ald, astride, self.seed, self._tick, None,
                                                  reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(),
-                                                 dstride, int(self.auto_reset), self._stream()), "aqua_rollout_f32")
+                                                 dstride, self._norm_ptr(), int(self.auto_reset), self._stream()),
+                            "aqua_rollout_f32")
         self._tick += steps
         return reward, term
 
@@ -317,7 +330,7 @@ class BatchedAqua(object):
                     rc = lib.aqua_rollout_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
                                               self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
                                               steps, aptr, kind, ald, astride, self.seed, 0, tb, reward.data_ptr(),
-                                              term.data_ptr(), ostride, done.data_ptr(), dstride,
+                                              term.data_ptr(), ostride, done.data_ptr(), dstride, self._norm_ptr(),
                                               int(self.auto_reset), s)
                 if rc == 0:
                     rc = lib.aqua_tick_advance(tb, steps, s)

@@ -60,7 +60,6 @@ def build_variant(name, flags, verbose=False):
 
 if __name__ == "__main__":
     if "--variants" in sys.argv:
-        for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("lds", ["-DAQUA_OBST_LDS=1"]),
-                            ("stamps", ["-DAQUA_STAMPS=1"]), ("philox7", ["-DAQUA_PHILOX_ROUNDS=7"])):
+        for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("lds", ["-DAQUA_OBST_LDS=1"]), ("stamps", ["-DAQUA_STAMPS=1"])):
             print(build_variant(name, flags, verbose=True))
     print(build_hip(force="--force" in sys.argv, verbose=True))

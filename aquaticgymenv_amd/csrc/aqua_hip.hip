@@ -47,6 +47,7 @@ struct StepArgs {
     float* reward;
     uint8_t* term;
     uint64_t* done_bits;
+    float* obs_norm;                     // optional [5][ld]: the observation scaled as the reference's AquaStateNormalizer
     const void* obst_blob;
     const uint64_t* tick_base;
     uint64_t seed, tick;
@@ -217,9 +218,6 @@ __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u
 #ifndef AQUA_STAMPS
 #define AQUA_STAMPS 0
 #endif
-#ifndef AQUA_WAVE_RESET
-#define AQUA_WAVE_RESET 0
-#endif
 #ifndef AQUA_WORKER_PRIO
 #define AQUA_WORKER_PRIO 1
 #endif
@@ -275,6 +273,19 @@ __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_
             w0[2 * p + 1] = r[2]; w1[2 * p + 1] = r[3];
         }
     }
+}
+
+// Optional fused epilogue: the observation as main/impl/utils.py:15-33 (AquaStateNormalizer) hands it to the DQN --
+// obs / (high - low) with 0.5 added to the angle: x/100, y/100, theta/(2 pi) + 0.5, gx/100, gy/100.
+__device__ __forceinline__ void write_norm(const StepArgs& a, int64_t i, float x, float y, float th, float gx, float gy)
+{
+    if (a.obs_norm == nullptr) return;
+    float* const o = a.obs_norm + i;
+    o[0 * a.ld] = x * 0.01f;
+    o[1 * a.ld] = y * 0.01f;
+    o[2 * a.ld] = fmaf(th, 0.15915494309189535f, 0.5f);
+    o[3 * a.ld] = gx * 0.01f;
+    o[4 * a.ld] = gy * 0.01f;
 }
 
 // reward / term / packed done bits of one wavefront's worlds
@@ -429,35 +440,6 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
     uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
     constexpr uint32_t own_reset_mask = 0;
-#if AQUA_WAVE_RESET
-    // variant: every wavefront re-seeds its own finished worlds right away (no list, no barrier)
-    if (a.auto_reset) {
-        skip_mask = done_mask;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            uint64_t m = __ballot((done_mask >> j) & 1u);
-            while (m != 0) {
-                int owner = -1;
-#pragma unroll
-                for (int g = 0; g < 64 / RESET_GROUP; ++g) {
-                    const int o = m ? __builtin_ctzll(m) : -1;
-                    if (lane / RESET_GROUP == g) owner = o;
-                    m &= m - 1;
-                }
-                const bool active = owner >= 0;
-                const uint32_t i = ((threadIdx.x & ~63u) + (active ? owner : 0)) * VEC + j;
-                const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
-                                                                tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
-                if (active && (lane & (RESET_GROUP - 1)) == 0) {
-                    row0[0 * ld + i] = e.x; row0[1 * ld + i] = e.y; row0[2 * ld + i] = e.th;
-                    row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
-                    row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
-                    trow[i] = e.t;
-                }
-            }
-        }
-    }
-#else
     if (a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
@@ -483,10 +465,10 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
                 row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
                 row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
                 trow[i] = e.t;
+                write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy);
             }
         }
     }
-#endif
     AQUA_STAMP(6);          // group re-seeding done
 
     if (skip_mask == 0 && own_reset_mask == 0 && full) {
@@ -496,6 +478,10 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         store_row<VEC, true>(row0 + 5 * ld, off, rem, wx);
         store_row<VEC, true>(row0 + 6 * ld, off, rem, wy);
         store_row<VEC, true>(trow, off, rem, t);
+        if (a.obs_norm != nullptr) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) write_norm(a, tile + off + j, x[j], y[j], th[j], gx[j], gy[j]);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -504,6 +490,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
                 row0[0 * ld + i] = x[j]; row0[1 * ld + i] = y[j]; row0[2 * ld + i] = th[j];
                 row0[5 * ld + i] = wx[j]; row0[6 * ld + i] = wy[j];
                 trow[i] = t[j];
+                write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j]);
             }
         }
     }
@@ -586,6 +573,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
                 row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
                 row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
                 trow[i] = e.t;
+                write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy);
             }
         }
         AQUA_RTSTAMP(2);
@@ -651,6 +639,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         row0[0 * ld + off] = e.x; row0[1 * ld + off] = e.y; row0[2 * ld + off] = e.th;
         row0[5 * ld + off] = e.wx; row0[6 * ld + off] = e.wy;
         trow[off] = done ? -1 : e.t;
+        write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
     }
     AQUA_RTSTAMP(2);
 }
@@ -1065,7 +1054,7 @@ int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t
                   float* state, int64_t ld, int32_t* time, const void* action, int action_kind,
                   int64_t action_ld, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t tick,
                   const uint64_t* tick_base_dev, float* reward, uint8_t* term, uint64_t* done_bits,
-                  int auto_reset, void* stream)
+                  float* obs_norm, int auto_reset, void* stream)
 {
     StepArgs a;
     int rc = fill_args(a, p, obst_blob_dev, K, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
@@ -1076,7 +1065,8 @@ int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t
     if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
     if (N == 0) return 0;
     a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
-    a.reward = reward; a.term = term; a.done_bits = done_bits; a.auto_reset = auto_reset;
+    a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = auto_reset;
+    if (obs_norm != nullptr && !aligned(obs_norm, 4)) return fail(AQUA_E_ALIGN, "obs_norm must be 4-byte aligned");
     const int vec = pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, N, env_offset);
     const hipError_t e = launch_step_any(a, action_kind, vec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_step_f32 launch");
@@ -1099,7 +1089,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
                      float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
                      int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
                      const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
-                     uint64_t* done_bits, int64_t done_step_stride, int auto_reset, void* stream)
+                     uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, void* stream)
 {
     StepArgs a;
     int rc = fill_args(a, p, obst_blob_dev, K, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
@@ -1109,7 +1099,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
     if (T < 0 || action_step_stride < 0 || out_step_stride < 0 || done_step_stride < 0)
         return fail(AQUA_E_INVALID, "negative T or stride");
     if (N == 0 || T == 0) return 0;
-    a.action_ld = action_ld; a.auto_reset = auto_reset;
+    a.action_ld = action_ld; a.auto_reset = auto_reset; a.obs_norm = obs_norm;
     const size_t esz = action_elem_bytes(action_kind);
     for (int64_t t = 0; t < T; ++t) {
         a.tick = tick + static_cast<uint64_t>(t);

@@ -100,6 +100,9 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
  *                   it on the device so a captured graph can be replayed with fresh noise.
  *   reward        : float32[N]; term: uint8[N] (AQUA_TERM_*); done_bits: uint64[ceil(N/64)] or NULL,
  *                   bit (i % 64) of word (i / 64) = done flag of local world i (wavefront ballot).
+ *   obs_norm      : NULL, or float32 [5][ld]: fused epilogue that also writes the new observation scaled as the
+ *                   reference's AquaStateNormalizer does before the DQN sees it (main/impl/utils.py:15-33):
+ *                   x/100, y/100, theta/(2 pi) + 0.5, gx/100, gy/100 (+20 B written per world-step).
  *   auto_reset    : AQUA_RESET_NONE      -> the reference's behaviour: no freeze, no reset.
  *                   AQUA_RESET_SAME_STEP -> worlds that finished are re-initialised in the same launch exactly as
  *                   aqua_reset_f32(mask = term != 0) would; reward/term/done_bits still describe the step
@@ -113,7 +116,7 @@ int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t
                   float* state, int64_t ld, int32_t* time, const void* action, int action_kind,
                   int64_t action_ld, const float* noise, int64_t noise_ld, uint64_t seed, uint64_t tick,
                   const uint64_t* tick_base_dev, float* reward, uint8_t* term, uint64_t* done_bits,
-                  int auto_reset, void* stream);
+                  float* obs_norm, int auto_reset, void* stream);
 
 /*
  * Masked reset: replaces AquaEnv.reset() (aqua.py:100-126) for the worlds with mask[i] != 0
@@ -135,7 +138,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
                      float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
                      int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
                      const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
-                     uint64_t* done_bits, int64_t done_step_stride, int auto_reset, void* stream);
+                     uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, void* stream);
 
 /*
  * The same T steps fused into ONE launch: pose, goal, wave and time stay in registers between

@@ -78,20 +78,22 @@ def test_argument_validation_without_touching_a_device(capi):
     addr = ctypes.addressof(buf)
     # N = 0 is a no-op that returns before any HIP call
     assert lib.aqua_step_f32(ctypes.byref(p), None, 0, 0, 0, addr, 0, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr,
-                             None, 0, None) == 0
+                             None, None, 0, None) == 0
     assert lib.aqua_reset_f32(ctypes.byref(p), None, 0, 0, 0, addr, 0, addr, None, 1, 0, None, None) == 0
     # bad arguments -> AQUA_E_INVALID (-1) / AQUA_E_ALIGN (-2) with a message
-    assert lib.aqua_step_f32(None, None, 0, 8, 0, addr, 8, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr, None, 0,
-                             None) == -1
+    assert lib.aqua_step_f32(None, None, 0, 8, 0, addr, 8, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr, None, None,
+                             0, None) == -1
     assert b"params" in lib.aqua_last_error()
     assert lib.aqua_step_f32(ctypes.byref(p), None, 0, 8, 0, addr, 4, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr,
-                             None, 0, None) == -1          # ld < N
+                             None, None, 0, None) == -1    # ld < N
     assert lib.aqua_step_f32(ctypes.byref(p), None, 3, 8, 0, addr, 8, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr,
-                             None, 0, None) == -1          # K > 0 without a table
+                             None, None, 0, None) == -1    # K > 0 without a table
     assert lib.aqua_step_f32(ctypes.byref(p), None, 0, 8, 0, addr, 8, addr, addr, 9, 0, None, 0, 1, 0, None, addr, addr,
-                             None, 0, None) == -1          # unknown action kind
+                             None, None, 0, None) == -1    # unknown action kind
     assert lib.aqua_step_f32(ctypes.byref(p), None, 0, 8, 0, addr + 2, 8, addr, addr, 0, 0, None, 0, 1, 0, None, addr,
-                             addr, None, 0, None) == -2    # misaligned state
+                             addr, None, None, 0, None) == -2    # misaligned state
+    assert lib.aqua_step_f32(ctypes.byref(p), None, 0, 8, 0, addr, 8, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr,
+                             None, None, 3, None) == -1    # auto_reset outside 0..2
     assert lib.aqua_set_vector_width(3) == -1
     assert lib.aqua_set_vector_width(0) in (0, 1, 2, 4)
     with pytest.raises(ValueError):

@@ -454,6 +454,28 @@ def test_bearing_policy_reproduces_the_reference_success_rate(torch):
         assert abs(ref_steps.mean() - steps.mean()) < 4 * sem + 1.0
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["no_reset", "same_step", "next_step"])
+def test_normalised_observation_epilogue(torch, mode):
+    """fused epilogue == main/impl/utils.py:15-33 (AquaStateNormalizer): obs / (high - low), angle + 0.5 --
+    also for the worlds re-seeded inside the launch."""
+    from aquaticgymenv_amd import presets
+    n = 5000
+    env = _make(torch, n, presets.BENCH8, seed=55, auto_reset=mode, normalized_obs=True)
+    env.reset()
+    scale = torch.tensor([100.0, 100.0, 2 * np.pi, 100.0, 100.0], device="cuda", dtype=torch.float64)
+    shift = torch.tensor([0.0, 0.0, 0.5, 0.0, 0.0], device="cuda", dtype=torch.float64)
+    for it in range(25):
+        obs, reward, term = env.step(sample_actions=True)
+        want = obs.to(torch.float64) / scale + shift
+        assert float((env.obs_norm.to(torch.float64) - want).abs().max()) < 2e-7
+    reward, term = env.rollout(10, keep_all=False)
+    want = env.obs.to(torch.float64) / scale + shift
+    assert float((env.obs_norm.to(torch.float64) - want).abs().max()) < 2e-7
+    plain = _make(torch, n, presets.BENCH8, seed=55, auto_reset=mode)
+    with pytest.raises(RuntimeError):
+        plain.obs_norm
+
+
 def test_done_mask_exchange_on_device(torch):
     """the N > 1 plumbing on one GPU (world size 1): side stream, event ordering, double buffer; the gathered
     block equals the ballot words the kernels wrote and those equal term != 0."""
