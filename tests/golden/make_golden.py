@@ -472,6 +472,30 @@ def gen_policy_stats(mod):
     return out
 
 
+def gen_dqn_fixture():
+    """weights of the reference's two trained DQN policies (example_policies/*/models/model-000NN, Keras
+    SavedModel variables read with aquaticgymenv_amd.tf_import -- TensorFlow is not installable here) and the
+    statistics of the reference's own 2 x 1000 evaluation runs (example_policies/test_results.pickle, the
+    numbers quoted in the reference's report: 93.8 % / 66.7 % success).  Numbers only."""
+    import pandas as pd
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from aquaticgymenv_amd.tf_import import read_checkpoint, dense_stack
+    root = "/root/reference/example_policies"
+    out = {}
+    for tag, sub in (("no_obs", "example_no_obs/models/model-00030"), ("with_obs", "example_with_obs/models/model-00032")):
+        layers = dense_stack(read_checkpoint(os.path.join(root, sub, "variables")))
+        for li, (k, b) in enumerate(layers):
+            out["%s_kernel%d" % (tag, li)] = k.astype(np.float32)
+            out["%s_bias%d" % (tag, li)] = b.astype(np.float32)
+    df = pd.read_pickle(os.path.join(root, "test_results.pickle"))
+    for tag, label in (("no_obs", "No obstacles"), ("with_obs", "With obstacles")):
+        rows = df[df["Environment"] == label]
+        out["%s_published_success" % tag] = np.asarray(rows["Success"], dtype=np.uint8)
+        out["%s_published_reward" % tag] = np.asarray(rows["Reward"], dtype=np.float64)
+        print("published %-9s n=%d success %.3f mean reward %.2f" % (tag, len(rows), rows["Success"].mean(), rows["Reward"].mean()))
+    return out
+
+
 def time_reference(mod):
     print("reference step() timing in this container (1 core, random actions, reset on done)")
     for ci in (0, 3, 4):
@@ -514,6 +538,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "traj_golden.npz"), **gen_trajectories(mod, rng))
     np.savez_compressed(os.path.join(HERE, "reset_golden.npz"), **gen_resets(mod))
     np.savez_compressed(os.path.join(HERE, "policy_golden.npz"), **gen_policy_stats(mod))
+    np.savez_compressed(os.path.join(HERE, "dqn_policies.npz"), **gen_dqn_fixture())
     terms = np.bincount(cols["term"], minlength=4)
     print("rows", len(rows), "hand", n_hand, "term histogram", terms.tolist())
     band = (np.abs(cols["m_border"]) < 1e-4) | (np.abs(cols["m_obst"]) < 1e-4) | (np.abs(cols["m_goal"]) < 1e-4)

@@ -476,6 +476,46 @@ def test_normalised_observation_epilogue(torch, mode):
         plain.obs_norm
 
 
+@pytest.mark.parametrize("tag,obstacles", [("no_obs", False), ("with_obs", True)])
+def test_trained_dqn_policies_reach_the_published_success_rates(torch, tag, obstacles):
+    """The reference's only published numbers (Report p.4, example_policies/test_results.pickle: 93.8 % success
+    without obstacles with checkpoint 30, 66.7 % with the default obstacles and checkpoint 32, 1000 runs each)
+    replayed on the batched path: Keras weights read without TensorFlow (tests/golden/dqn_policies.npz), greedy
+    5-64-64-3 MLP on the device fed by the fused AquaStateNormalizer epilogue, one episode per world."""
+    import os
+    from tests._golden import GOLDEN
+    from aquaticgymenv_amd.tf_import import GreedyQPolicy
+    from aquaticgymenv_amd.batched import BatchedAqua
+    z = np.load(os.path.join(GOLDEN, "dqn_policies.npz"))
+    layers = [(z["%s_kernel%d" % (tag, i)], z["%s_bias%d" % (tag, i)]) for i in range(3)]
+    n = 16384
+    env = BatchedAqua(n, obstacles=obstacles, seed=9001, auto_reset=False, normalized_obs=True, device="cuda:0")
+    env.reset()
+    scale = torch.tensor([100.0, 100.0, 2 * np.pi, 100.0, 100.0], device="cuda")
+    shift = torch.tensor([0.0, 0.0, 0.5, 0.0, 0.0], device="cuda")
+    policy = GreedyQPolicy(layers, "cuda:0")
+    first = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    total = torch.zeros(n, dtype=torch.float32, device="cuda")
+    obs_norm = env.obs / scale + shift                 # after reset(); afterwards the kernels' fused epilogue supplies it
+    for step in range(1001):
+        action = policy(obs_norm)
+        obs, reward, term = env.step(action)
+        alive = first == 0
+        total += torch.where(alive, reward, torch.zeros_like(reward))
+        first = torch.where(alive, term, first)
+        obs_norm = env.obs_norm
+        if step % 100 == 99 and int((first == 0).sum()) == 0:
+            break
+    assert int((first == 0).sum()) == 0
+    success = float((first == 3).float().mean())
+    reward_mean = float(total.mean())
+    pub_s, pub_r = z["%s_published_success" % tag], z["%s_published_reward" % tag]
+    sigma = np.sqrt(pub_s.mean() * (1 - pub_s.mean()) / pub_s.shape[0])
+    assert abs(success - pub_s.mean()) < 4 * sigma + 0.01, "success %.4f vs published %.4f" % (success, pub_s.mean())
+    sem = pub_r.std() / np.sqrt(pub_r.shape[0])
+    assert abs(reward_mean - pub_r.mean()) < 4 * sem + 0.5, "mean reward %.3f vs published %.3f" % (reward_mean, pub_r.mean())
+
+
 def test_done_mask_exchange_on_device(torch):
     """the N > 1 plumbing on one GPU (world size 1): side stream, event ordering, double buffer; the gathered
     block equals the ballot words the kernels wrote and those equal term != 0."""
