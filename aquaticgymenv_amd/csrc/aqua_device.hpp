@@ -68,6 +68,7 @@ struct StepConst {              // wave-uniform
     int time_limit;             // aqua.py:91
     int K, Kc;                  // obstacles, of which the first Kc are circles
     float band2, band2_tight;
+    uint32_t touch;             // OR of one word per table cache line (see make_const): a dependency, not data
     ObstPtr obst;               // float32 table (scalar-loaded from the blob, or the LDS copy)
     const double* obst64;       // global float64 rows [K][5] (exact path)
 };
@@ -114,6 +115,42 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
         if constexpr (SCALAR_KEY) asm volatile("" : "+s"(k0), "+s"(k1));
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// The same ten rounds computed ONCE per pair of adjacent lanes (2i, 2i + 1) that share a counter: the even
+// lane carries (c0, c1) and forms the M0 product, the odd lane carries (c2, c3) and forms the M1 product; a
+// round swaps the two products between the lanes (DPP quad_perm [1, 0, 3, 2], no LDS).  One quarter-rate
+// 32x32->64 multiply per lane and round instead of two.  Returns the lane's half of the block: words (0, 1)
+// on the even lane, (2, 3) on the odd lane -- bit for bit philox4x32_10's.  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t swap_pair(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ void philox4x32_10_pair(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                                                   uint32_t c3, bool odd, uint32_t& w0, uint32_t& w1)
+{
+    uint32_t a = odd ? c2 : c0, b = odd ? c3 : c1, key = odd ? k1 : k0;
+    const uint32_t mult = odd ? 0xCD9E8D57u : 0xD2511F53u;
+    const uint32_t bump = odd ? 0xBB67AE85u : 0x9E3779B9u;
+#pragma unroll
+    for (int r = 0; r < AQUA_PHILOX_ROUNDS; ++r) {
+        const uint64_t p = static_cast<uint64_t>(a) * mult;
+        const uint32_t other_hi = swap_pair(static_cast<uint32_t>(p >> 32));
+        const uint32_t other_lo = swap_pair(static_cast<uint32_t>(p));
+        a = other_hi ^ b ^ key;          // even: hi(M1 c2) ^ c1 ^ k0    odd: hi(M0 c0) ^ c3 ^ k1
+        b = other_lo;                    // even: lo(M1 c2)              odd: lo(M0 c0)
+        key += bump;
+    }
+    w0 = a; w1 = b;
+}
+
+__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, uint32_t attempt,
+                                          bool odd, uint32_t& w0, uint32_t& w1)
+{
+    const uint32_t c3 = (static_cast<uint32_t>(tick >> 32) & 0xFFFFu) | ((attempt & 0xFFu) << 16) | (stream << 24);
+    philox4x32_10_pair(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), static_cast<uint32_t>(env),
+                       static_cast<uint32_t>(env >> 32), static_cast<uint32_t>(tick), c3, odd, w0, w1);
 }
 
 // SCALAR_KEY: the caller guarantees `seed` is wave-uniform and lives in SGPRs (kernel arguments)

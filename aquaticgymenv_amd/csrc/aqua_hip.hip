@@ -54,6 +54,7 @@ struct StepArgs {
     int64_t N, env_offset;
     // rollout only
     int64_t T, action_step_stride, out_step_stride;
+    int64_t reseed_blocks;               // next-step kernel: the first blocks of the grid re-seed (see step_ns_kernel)
     int K, waves, time_limit, auto_reset, random_boat, random_goal;
     float W, sigma;
 };
@@ -62,12 +63,45 @@ struct StepArgs {
 // `p` is a wave-uniform row pointer already advanced to the tile, `off` the lane's element offset
 // inside the tile (32-bit), `rem` the number of valid elements from p on.  FULL tiles carry no guards:
 // the loads of a lane are issued back to back as global_load_dword{,x2,x4} v, voffset, s[base].
+// AQUA_LOAD_HINT / AQUA_STORE_HINT (build-time experiments): 0 plain, 1 non-temporal, 2 agent-scope (write-through
+// past the XCD's L2 for stores, L2-bypassing for loads)
+#ifndef AQUA_LOAD_HINT
+#define AQUA_LOAD_HINT 0
+#endif
+#ifndef AQUA_STORE_HINT
+#define AQUA_STORE_HINT 2
+#endif
+template <typename T>
+__device__ __forceinline__ T ld1(const T* p)
+{
+#if AQUA_LOAD_HINT == 1
+    return __builtin_nontemporal_load(p);
+#elif AQUA_LOAD_HINT == 2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void st1(T* p, T v)
+{
+#if AQUA_STORE_HINT == 1
+    __builtin_nontemporal_store(v, p);
+#elif AQUA_STORE_HINT == 2
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif AQUA_STORE_HINT == 3
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *p = v;
+#endif
+}
+
 template <int VEC, bool FULL, typename T>
 __device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, int64_t rem, T (&v)[VEC])
 {
     if constexpr (FULL) {
         if constexpr (VEC == 1) {
-            v[0] = p[off];
+            v[0] = ld1(p + off);
         } else {
             struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
             const Pack q = *reinterpret_cast<const Pack*>(p + off);
@@ -85,7 +119,7 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64
 {
     if constexpr (FULL) {
         if constexpr (VEC == 1) {
-            p[off] = v[0];
+            st1(p + off, v[0]);
         } else {
             struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
             Pack q;
@@ -149,13 +183,27 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K;
     k.obst = obst;
-    k.Kc = 0; k.band2 = 0.0f; k.band2_tight = 0.0f;
-    if (a.K > 0) {                       // header fields: uniform scalar loads
+    k.Kc = 0; k.band2 = 0.0f; k.band2_tight = 0.0f; k.touch = 0;
+#ifdef AQUA_EXP_NO_DEREF
+    if (a.K > 0) { k.Kc = 4; k.band2 = 3.1e-3f; k.band2_tight = 2.0e-4f; }   // timing experiment only
+    else
+#endif
+    if (a.obst_blob != nullptr) {        // header fields: uniform scalar loads (the pointer is NULL when K == 0)
         const ObstHeader __attribute__((address_space(4)))* h =
             (const ObstHeader __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
         k.Kc = h->n_circles;
         k.band2 = h->band2;
         k.band2_tight = h->band2_tight;
+        // Touch the table's cache lines now (rows 2l - 1 and 2l share line l; row 0 shares the header's): the
+        // scalar cache starts every launch cold, and the row loads of the obstacle passes are issued two rows
+        // at a time -- each of them would otherwise be a miss of its own, one memory round trip after the other.
+        const uint32_t __attribute__((address_space(4)))* w = (const uint32_t __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
+        uint32_t touch = 0;
+        if (a.K >= 2) touch |= w[16];
+        if (a.K >= 4) touch |= w[32];
+        if (a.K >= 6) touch |= w[48];
+        if (a.K >= 8) touch |= w[64];
+        k.touch = touch;
     }
     k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstHeader) +
                                                sizeof(ObstF) * a.K);
@@ -259,9 +307,17 @@ __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_
                                            uint32_t (&w0)[VEC], uint32_t (&w1)[VEC])
 {
     if constexpr (VEC == 1) {
+        const bool odd = (env0 & 1u) != 0;
+#ifndef AQUA_NO_PAIR_PHILOX
+        // lanes 2i and 2i + 1 hold the two worlds of one pair whenever the wavefront's first world is even
+        // (always, unless the caller's env_offset is odd): the pair then computes its block together
+        if (uni((static_cast<uint32_t>(env0) ^ threadIdx.x) & 1u) == 0u) {
+            draw_pair(seed, env0 >> 1, tick, stream, 0, odd, w0[0], w1[0]);
+            return;
+        }
+#endif
         uint32_t r[4];
         draw<SCALAR_KEY>(seed, env0 >> 1, tick, stream, 0, r);
-        const bool odd = (env0 & 1u) != 0;
         w0[0] = odd ? r[2] : r[0];
         w1[0] = odd ? r[3] : r[1];
     } else {
@@ -281,11 +337,11 @@ __device__ __forceinline__ void write_norm(const StepArgs& a, int64_t i, float x
 {
     if (a.obs_norm == nullptr) return;
     float* const o = a.obs_norm + i;
-    o[0 * a.ld] = x * 0.01f;
-    o[1 * a.ld] = y * 0.01f;
-    o[2 * a.ld] = fmaf(th, 0.15915494309189535f, 0.5f);
-    o[3 * a.ld] = gx * 0.01f;
-    o[4 * a.ld] = gy * 0.01f;
+    st1(o + 0 * a.ld, x * 0.01f);
+    st1(o + 1 * a.ld, y * 0.01f);
+    st1(o + 2 * a.ld, fmaf(th, 0.15915494309189535f, 0.5f));
+    st1(o + 3 * a.ld, gx * 0.01f);
+    st1(o + 4 * a.ld, gy * 0.01f);
 }
 
 // reward / term / packed done bits of one wavefront's worlds
@@ -317,14 +373,17 @@ __device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, u
     }
 }
 
+// Issues every load of a lane's worlds and consumes NOTHING: the time row first (the restart bookkeeping
+// waits for it alone, vmcnt counts in order), the action as loaded (fold_actions() clamps it later).
 template <int VEC, int AK, bool FULL>
 __device__ __forceinline__ void load_inputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, float (&x)[VEC],
                                             float (&y)[VEC], float (&th)[VEC], float (&gx)[VEC], float (&gy)[VEC],
-                                            float (&wx)[VEC], float (&wy)[VEC], int32_t (&t)[VEC], int (&aidx)[VEC],
+                                            float (&wx)[VEC], float (&wy)[VEC], int32_t (&t)[VEC], int64_t (&araw)[VEC],
                                             float (&avl)[VEC], float (&avr)[VEC], float (&u0)[VEC], float (&u1)[VEC])
 {
     const int64_t ld = a.ld;
     const float* const row0 = a.state + tile;
+    load_row<VEC, FULL>(a.time + tile, off, rem, t);
     load_row<VEC, FULL>(row0 + 0 * ld, off, rem, x);
     load_row<VEC, FULL>(row0 + 1 * ld, off, rem, y);
     load_row<VEC, FULL>(row0 + 2 * ld, off, rem, th);
@@ -332,22 +391,18 @@ __device__ __forceinline__ void load_inputs(const StepArgs& a, int64_t tile, uin
     load_row<VEC, FULL>(row0 + 4 * ld, off, rem, gy);
     load_row<VEC, FULL>(row0 + 5 * ld, off, rem, wx);
     load_row<VEC, FULL>(row0 + 6 * ld, off, rem, wy);
-    load_row<VEC, FULL>(a.time + tile, off, rem, t);
     if constexpr (AK == AQUA_ACT_U8) {
         uint8_t v[VEC];
         load_row<VEC, FULL>(static_cast<const uint8_t*>(a.action) + tile, off, rem, v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) aidx[j] = v[j] > 2 ? 2 : v[j];
+        for (int j = 0; j < VEC; ++j) araw[j] = v[j];
     } else if constexpr (AK == AQUA_ACT_I32) {
         int32_t v[VEC];
         load_row<VEC, FULL>(static_cast<const int32_t*>(a.action) + tile, off, rem, v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) aidx[j] = fold_index(v[j]);
+        for (int j = 0; j < VEC; ++j) araw[j] = v[j];
     } else if constexpr (AK == AQUA_ACT_I64) {
-        int64_t v[VEC];
-        load_row<VEC, FULL>(static_cast<const int64_t*>(a.action) + tile, off, rem, v);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) aidx[j] = fold_index(v[j]);
+        load_row<VEC, FULL>(static_cast<const int64_t*>(a.action) + tile, off, rem, araw);
     } else if constexpr (AK == AQUA_ACT_F32X2) {
         load_row<VEC, FULL>(static_cast<const float*>(a.action) + tile, off, rem, avl);
         load_row<VEC, FULL>(static_cast<const float*>(a.action) + a.action_ld + tile, off, rem, avr);
@@ -355,6 +410,38 @@ __device__ __forceinline__ void load_inputs(const StepArgs& a, int64_t tile, uin
     if (a.noise != nullptr) {
         load_row<VEC, FULL>(a.noise + tile, off, rem, u0);
         load_row<VEC, FULL>(a.noise + a.noise_ld + tile, off, rem, u1);
+    }
+}
+
+// Scheduling fence between the Philox draws and the first use of anything loaded: the draws (~280 cycles,
+// no memory operand) then always run in the shadow of the loads instead of after a wait for them.
+template <int VEC, int AK>
+__device__ __forceinline__ void hold_loads(float (&x)[VEC], float (&y)[VEC], float (&th)[VEC], float (&gx)[VEC],
+                                           float (&gy)[VEC], float (&wx)[VEC], float (&wy)[VEC], int64_t (&araw)[VEC],
+                                           float (&avl)[VEC], float (&avr)[VEC])
+{
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        asm volatile("" : "+v"(x[j]), "+v"(y[j]), "+v"(th[j]), "+v"(gx[j]), "+v"(gy[j]), "+v"(wx[j]), "+v"(wy[j]));
+        if constexpr (AK == AQUA_ACT_U8 || AK == AQUA_ACT_I32) {
+            int lo = static_cast<int>(araw[j]);
+            asm volatile("" : "+v"(lo));
+            araw[j] = lo;
+        } else if constexpr (AK == AQUA_ACT_I64) {
+            asm volatile("" : "+v"(araw[j]));
+        } else if constexpr (AK == AQUA_ACT_F32X2) {
+            asm volatile("" : "+v"(avl[j]), "+v"(avr[j]));
+        }
+    }
+}
+
+template <int VEC, int AK>
+__device__ __forceinline__ void fold_actions(const int64_t (&araw)[VEC], int (&aidx)[VEC])
+{
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if constexpr (AK == AQUA_ACT_U8) aidx[j] = araw[j] > 2 ? 2 : static_cast<int>(araw[j]);
+        else if constexpr (AK == AQUA_ACT_I32 || AK == AQUA_ACT_I64) aidx[j] = fold_index(araw[j]);
     }
 }
 
@@ -373,12 +460,13 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     float x[VEC], y[VEC], th[VEC], gx[VEC], gy[VEC], wx[VEC], wy[VEC], u0[VEC], u1[VEC], avl[VEC], avr[VEC];
     int32_t t[VEC];
     int aidx[VEC];
+    int64_t araw[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { aidx[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; u0[j] = 0.0f; u1[j] = 0.0f; }
+    for (int j = 0; j < VEC; ++j) { aidx[j] = 2; araw[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; u0[j] = 0.0f; u1[j] = 0.0f; }
     const bool full = rem >= TILE_WORLDS;                // uniform: a whole tile carries no per-lane guards
     AQUA_RTSTAMP(0);
-    if (full) load_inputs<VEC, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
-    else load_inputs<VEC, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, aidx, avl, avr, u0, u1);
+    if (full) load_inputs<VEC, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, araw, avl, avr, u0, u1);
+    else load_inputs<VEC, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, araw, avl, avr, u0, u1);
 
     const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
     if (a.noise == nullptr) {
@@ -396,6 +484,8 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             else { avl[j] = sample_thrust(w0[j]); avr[j] = sample_thrust(w1[j]); }
         }
     }
+    hold_loads<VEC, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
+    fold_actions<VEC, AK>(araw, aidx);
 
     if constexpr (AK == AQUA_ACT_BEARING) {
 #pragma unroll
@@ -407,6 +497,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     Motion mo[VEC];
     float x0[VEC], y0[VEC], th0[VEC], wx0[VEC], wy0[VEC];      // step inputs, kept for the exact path
     uint32_t knife_mask = 0, done_mask = 0;
+    asm volatile("" ::"s"(k.touch));                   // the table's lines are resident from here on
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         x0[j] = x[j]; y0[j] = y[j]; th0[j] = th[j]; wx0[j] = wx[j]; wy0[j] = wy[j];
@@ -461,10 +552,10 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
                                                             tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
-                row0[0 * ld + i] = e.x; row0[1 * ld + i] = e.y; row0[2 * ld + i] = e.th;
-                row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
-                row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
-                trow[i] = e.t;
+                st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
+                st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
+                st1(row0 + 5 * ld + i, e.wx); st1(row0 + 6 * ld + i, e.wy);
+                st1(trow + i, e.t);
                 write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy);
             }
         }
@@ -497,6 +588,17 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     AQUA_RTSTAMP(7);        // state stores issued (wall clock)
 }
 
+// tick of this launch.  The device-resident base is written only by tick_kernel, between launches, so it
+// is read through the scalar path (constant address space) like the obstacle table.
+__device__ __forceinline__ uint64_t launch_tick(const StepArgs& a)
+{
+#ifdef AQUA_EXP_NO_DEREF
+    return a.tick;                       // timing experiment only
+#endif
+    if (a.tick_base == nullptr) return a.tick;
+    return a.tick + *(const uint64_t __attribute__((address_space(4)))*)(uintptr_t)a.tick_base;
+}
+
 template <int VEC, int AK>
 __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs a)
 {
@@ -505,97 +607,170 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
     if (threadIdx.x == 0) sh.count = 0;
     const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     if (a.auto_reset) __syncthreads();
-    const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
+    const uint64_t tick = launch_tick(a);
     step_tile<VEC, AK>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
 // ------------------------------------------------------------------ one launch per step, next-step restart
 // auto_reset == 2 ("next-step", the Gymnasium >= 1.0 convention): a world that finishes at tick t keeps its
-// terminal state, is marked pending (time = -1) and is restarted DURING tick t + 1, when it does not step:
+// terminal state, is marked pending (negative time) and is restarted DURING tick t + 1, when it does not step:
 // that tick reports its fresh observation with reward 0 and term 0.  Nothing of the restart is then on the
-// step's dependency chain, so the re-seeding runs beside the main work instead of behind it: a workgroup
-// is NS_MAIN_WAVES wavefronts that step NS_TILE worlds plus NS_WORK_WAVES dedicated wavefronts that
-// re-seed the tile's pending worlds.  Main wavefronts load `time` first, append their pending worlds to
-// the LDS list, signal arrival (LDS counter, no barrier) and carry on; the workers wait for the last
-// arrival only.
+// step's dependency chain, and only ~2 % of the worlds restart in a step, so the launch is split by role:
+//
+//   blocks [0, R)      re-seed.  Block b reads the time row of worlds [b * NS_SCAN, (b + 1) * NS_SCAN), compacts the
+//                      pending ones into an LDS list (one private segment per wavefront, one barrier) and
+//                      re-seeds them NS_RESEED_GROUP lanes per world.  First in the grid: they start first.
+//   blocks [R, R + M)  step.  NS_TILE worlds each, one per lane, straight-line: loads, Philox in the loads'
+//                      shadow, fast path, stores.  No LDS, no barrier.
+//
+// The two roles share nothing inside a launch -- no barrier, no flag, and no assumption about which runs
+// first.  What keeps that race-free are the markers in the time row, which carry the parity of the tick that
+// wrote them:
+//     done_code(t)    = -1 - (t & 1)   the world finished at tick t and waits for its restart
+//     restart_code(t) = -3 - (t & 1)   the world was restarted during tick t (its time is 0 from tick t + 1 on)
+// At tick T the re-seeding blocks restart exactly the worlds marked done_code(T - 1) and mark them
+// restart_code(T); the stepping blocks step the worlds with time >= 0 or restart_code(T - 1) (time 0) and
+// leave every other marker alone (reward 0, term 0, nothing written).  Whether a stepping wavefront sees
+// done_code(T - 1) or the restart_code(T) that replaced it, it skips the world; a done_code(T) written by a
+// stepping wavefront of this launch is not what the scan is looking for.  (Ticks therefore advance by one
+// per step; after a jump in parity a marked world simply waits one more step.)
 #ifndef AQUA_NS_MAIN_WAVES
-#define AQUA_NS_MAIN_WAVES 6
+#define AQUA_NS_MAIN_WAVES 4
 #endif
-constexpr int NS_MAIN_WAVES = AQUA_NS_MAIN_WAVES, NS_WORK_WAVES = 2;
-constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = (NS_MAIN_WAVES + NS_WORK_WAVES) * 64;
+#ifndef AQUA_NS_SCAN_ROWS
+#define AQUA_NS_SCAN_ROWS 4
+#endif
+#ifndef AQUA_NS_RESEED_GROUP
+#define AQUA_NS_RESEED_GROUP 8
+#endif
+constexpr int NS_MAIN_WAVES = AQUA_NS_MAIN_WAVES;
+constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = NS_TILE;
+constexpr int NS_SCAN_ROWS = AQUA_NS_SCAN_ROWS, NS_SCAN = NS_SCAN_ROWS * NS_BLOCK;      // worlds per re-seeding block
+constexpr int NS_RESEED_GROUP = AQUA_NS_RESEED_GROUP;
+static_assert(NS_SCAN <= 65536, "list entries are 16-bit offsets");
 
-struct NsShared {
-    uint32_t count, arrived;
-    uint16_t list[NS_TILE];
+__device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static_cast<int32_t>(tick & 1u); }
+__device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
+
+struct NsReseedShared {
+    uint32_t count[NS_MAIN_WAVES];
+    uint16_t list[NS_MAIN_WAVES][NS_SCAN_ROWS * 64];
 };
+
+__device__ __forceinline__ void ns_reseed_block(const StepArgs& a, ObstF* s_obst, NsReseedShared& sh)
+{
+    __builtin_amdgcn_s_setprio(3);                      // the longest chain of the launch: issue first
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * NS_SCAN;
+    const int64_t ld = a.ld, rem = a.N - base;          // > 0
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t last = static_cast<uint32_t>(rem < NS_SCAN ? rem - 1 : NS_SCAN - 1);
+    float* const row0 = a.state + base;
+    int32_t* const trow = a.time + base;
+    int32_t tw[NS_SCAN_ROWS];
+#pragma unroll
+    for (int j = 0; j < NS_SCAN_ROWS; ++j) {            // the loads first
+        const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
+        tw[j] = ld1(trow + (i < last ? i : last));
+    }
+    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const uint64_t tick = launch_tick(a);
+    const int32_t restart = done_code(tick - 1);
+    AQUA_RTSTAMP(0);
+    uint32_t n_mine = 0;
+#pragma unroll
+    for (int j = 0; j < NS_SCAN_ROWS; ++j) {            // wavefront-private compaction: ballot + prefix count
+        const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
+#ifdef AQUA_NS_NOMAIN
+        const bool p = static_cast<int64_t>(i) < rem && tw[j] != restart &&
+                       ((static_cast<uint32_t>(base) + i) * 2654435761u + static_cast<uint32_t>(tick) * 40503u) % 54u == 0u;
+#else
+        const bool p = static_cast<int64_t>(i) < rem && tw[j] == restart;
+#endif
+        const uint64_t m = __ballot(p);
+        if (p) sh.list[wave][n_mine + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = static_cast<uint16_t>(i);
+        n_mine += static_cast<uint32_t>(__builtin_popcountll(m));
+    }
+    if (lane == 0) sh.count[wave] = n_mine;
+    __syncthreads();
+    uint32_t first[NS_MAIN_WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < NS_MAIN_WAVES; ++w) first[w + 1] = first[w] + sh.count[w];
+    const uint32_t n_pending = uni(first[NS_MAIN_WAVES]);
+    asm volatile("" ::"s"(k.touch));                   // the table's lines are resident from here on
+    AQUA_RTSTAMP(1);
+    constexpr uint32_t PER_WAVE = 64 / NS_RESEED_GROUP, PER_BLOCK = NS_MAIN_WAVES * PER_WAVE;
+    for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_pending; qb += PER_BLOCK) {
+        const uint32_t q = qb + (lane / NS_RESEED_GROUP);
+        const bool active = q < n_pending;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < NS_MAIN_WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+        const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
+        const EnvState e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + base) + i, tick,
+                                                            k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
+            st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
+            st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
+            st1(row0 + 5 * ld + i, e.wx); st1(row0 + 6 * ld + i, e.wy);
+            st1(trow + i, restart_code(tick));
+            write_norm(a, base + i, e.x, e.y, e.th, e.gx, e.gy);
+        }
+    }
+    AQUA_RTSTAMP(2);
+}
 
 template <int AK>
 __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
-    __shared__ NsShared sh;
-    if (threadIdx.x == 0) { sh.count = 0; sh.arrived = 0; }
-    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
-    __syncthreads();                                  // nothing has happened yet: every wavefront is here at once
-    const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
-    const int64_t tile = static_cast<int64_t>(blockIdx.x) * NS_TILE;
-    const int64_t ld = a.ld, rem = a.N - tile;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* const row0 = a.state + tile;
-    int32_t* const trow = a.time + tile;
-
-    if (wave >= NS_MAIN_WAVES) {
-        // ---- worker wavefront: re-seed the worlds that finished last tick
-#ifdef AQUA_NS_NOWORK
-        return;                              // timing experiment only
+    __shared__ NsReseedShared sh;
+    AQUA_RTSTAMP(3);        // wavefront started
+    if (static_cast<int64_t>(blockIdx.x) < a.reseed_blocks) {
+#ifndef AQUA_NS_NOWORK                       // (timing experiment: what the re-seeding blocks cost the launch)
+        ns_reseed_block(a, s_obst, sh);
 #endif
-#if AQUA_WORKER_PRIO
-        __builtin_amdgcn_s_setprio(3);      // the worker's chain is the longest in the workgroup: let it issue first
-#endif
-        AQUA_RTSTAMP(0);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&sh.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   static_cast<uint32_t>(NS_MAIN_WAVES) && spins < (1u << 22)) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-        }
-        AQUA_RTSTAMP(1);
-        const uint32_t n_pending = sh.count;
-        constexpr uint32_t GROUPS = NS_WORK_WAVES * (64 / RESET_GROUP);
-        for (uint32_t qb = (wave - NS_MAIN_WAVES) * (64 / RESET_GROUP); qb < n_pending; qb += GROUPS) {
-            const uint32_t q = qb + (lane / RESET_GROUP);
-            const bool active = q < n_pending;
-            const uint32_t i = sh.list[active ? q : 0];
-            const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
-                                                            tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
-            if (active && (lane & (RESET_GROUP - 1)) == 0) {
-                row0[0 * ld + i] = e.x; row0[1 * ld + i] = e.y; row0[2 * ld + i] = e.th;
-                row0[3 * ld + i] = e.gx; row0[4 * ld + i] = e.gy;
-                row0[5 * ld + i] = e.wx; row0[6 * ld + i] = e.wy;
-                trow[i] = e.t;
-                write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy);
-            }
-        }
-        AQUA_RTSTAMP(2);
         return;
     }
-
-    // ---- main wavefront
-    AQUA_RTSTAMP(0);
+#ifdef AQUA_NS_NOMAIN
+    return;                                  // (timing experiment: the re-seeding blocks alone)
+#endif
+    // ---- stepping block.  Every load goes out first: the addresses need the kernel arguments only, while
+    // the table header and the tick base below cost another scalar-memory round trip.  One straight-line
+    // sequence for whole and ragged tiles (a lane past the end reads the tile's last world and never writes).
+    const int64_t tile = (static_cast<int64_t>(blockIdx.x) - a.reseed_blocks) * NS_TILE;
+    const int64_t ld = a.ld, rem = a.N - tile;
+    const int lane = threadIdx.x & 63;
+    float* const row0 = a.state + tile;
+    int32_t* const trow = a.time + tile;
+    const uint32_t last = static_cast<uint32_t>(rem < NS_TILE ? rem - 1 : NS_TILE - 1);    // rem >= 1
     const uint32_t off = threadIdx.x;                  // < NS_TILE
     const bool valid = static_cast<int64_t>(off) < rem;
-    int32_t t0 = valid ? trow[off] : 0;
-    const bool pending = valid && t0 < 0;
-    if (pending) sh.list[atomicAdd(&sh.count, 1u)] = static_cast<uint16_t>(off);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(&sh.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-
+    const uint32_t o = off < last ? off : last;        // umin: still a small 32-bit lane offset (saddr + voffset loads)
     float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
-    int32_t tdummy[1];
+    int32_t tin[1];
+    int64_t araw[1] = {2};
     int aidx[1] = {2};
-    if (rem >= NS_TILE) load_inputs<1, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, tdummy, aidx, avl, avr, u0, u1);
-    else load_inputs<1, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, tdummy, aidx, avl, avr, u0, u1);
-
+    tin[0] = ld1(trow + o);
+    x[0] = ld1(row0 + 0 * ld + o); y[0] = ld1(row0 + 1 * ld + o); th[0] = ld1(row0 + 2 * ld + o);
+    gx[0] = ld1(row0 + 3 * ld + o); gy[0] = ld1(row0 + 4 * ld + o);
+    wx[0] = ld1(row0 + 5 * ld + o); wy[0] = ld1(row0 + 6 * ld + o);
+    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld1(static_cast<const uint8_t*>(a.action) + tile + o);
+    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld1(static_cast<const int32_t*>(a.action) + tile + o);
+    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld1(static_cast<const int64_t*>(a.action) + tile + o);
+    else if constexpr (AK == AQUA_ACT_F32X2) {
+        avl[0] = ld1(static_cast<const float*>(a.action) + tile + o);
+        avr[0] = ld1(static_cast<const float*>(a.action) + a.action_ld + tile + o);
+    }
+    if (a.noise != nullptr) {                          // injected noise (tests)
+        u0[0] = ld1(a.noise + tile + o);
+        u1[0] = ld1(a.noise + a.noise_ld + tile + o);
+    }
+    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const uint64_t tick = launch_tick(a);
+    AQUA_RTSTAMP(0);
+    // The draws need no loaded value: they run in the shadow of the loads.
     const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
     if (a.noise == nullptr) {
         uint32_t w0[1], w1[1];
@@ -608,6 +783,12 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
         else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
     }
+    asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));   // scheduling fence, see hold_loads()
+    hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
+    AQUA_RTSTAMP(4);        // draws done, loads back
+    fold_actions<1, AK>(araw, aidx);
+    const int32_t t0 = tin[0] == restart_code(tick - 1) ? 0 : tin[0];   // restarted last tick: steps from 0
+    const bool pending = valid && t0 < 0;              // any other marker: the world does not step
     if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
     EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
@@ -616,29 +797,30 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     uint32_t code;
     const bool live = valid && !pending;
     AQUA_RTSTAMP(1);
+    asm volatile("" ::"s"(k.touch));                   // the table's lines are resident from here on
     const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
     if (__any(knife)) {
         if (knife) {
-            const ExactOut o = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
-                                          k.obst, k.band2, k.time_limit);
-            e.x = o.x; e.y = o.y; e.th = o.th; rew = o.reward; code = o.term;
+            const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
+                                           k.obst, k.band2, k.time_limit);
+            e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
         }
     }
     if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
     const bool done = code != 0u;
     if (valid) {
-        a.reward[tile + off] = rew;
-        a.term[tile + off] = static_cast<uint8_t>(code);
+        st1(a.reward + tile + off, rew);
+        st1(a.term + tile + off, static_cast<uint8_t>(code));
     }
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done);
         const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
         if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
     }
-    if (live) {                                        // pending worlds are written by the workers
-        row0[0 * ld + off] = e.x; row0[1 * ld + off] = e.y; row0[2 * ld + off] = e.th;
-        row0[5 * ld + off] = e.wx; row0[6 * ld + off] = e.wy;
-        trow[off] = done ? -1 : e.t;
+    if (live) {                                        // pending worlds are written by the re-seeding blocks
+        st1(row0 + 0 * ld + off, e.x); st1(row0 + 1 * ld + off, e.y); st1(row0 + 2 * ld + off, e.th);
+        st1(row0 + 5 * ld + off, e.wx); st1(row0 + 6 * ld + off, e.wy);
+        st1(trow + off, done ? done_code(tick) : e.t);
         write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
     }
     AQUA_RTSTAMP(2);
@@ -679,7 +861,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
     const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
-    const uint64_t tick0 = a.tick + (a.tick_base ? *a.tick_base : 0ull);
+    const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     // whole wavefronts iterate together (ballots and shuffles inside); lanes past N are inert
     for (int64_t wbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + (threadIdx.x & ~63); wbase < N;
@@ -689,12 +871,21 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
         const int64_t ic = valid ? i : N - 1;
         EnvState e{a.state[0 * ld + ic], a.state[1 * ld + ic], a.state[2 * ld + ic], a.state[3 * ld + ic],
                    a.state[4 * ld + ic], a.state[5 * ld + ic], a.state[6 * ld + ic], a.time[ic]};
-        const uint64_t env = static_cast<uint64_t>(a.env_offset + ic);
+        const uint64_t env = static_cast<uint64_t>(a.env_offset + i);        // the lane's own index (pairs of lanes draw together)
         for (int64_t s = 0; s < a.T; ++s) {
             const uint64_t tick = tick0 + static_cast<uint64_t>(s);
-            // next-step restart: a world marked pending does not move this tick, it is re-seeded instead
-            const bool pending = a.auto_reset == AQUA_RESET_NEXT_STEP && valid && e.t < 0;
-            if (a.auto_reset == AQUA_RESET_NEXT_STEP && __any(pending)) wave_reseed(e, pending, a, k, tick, wbase);
+            // next-step restart, with the markers of step_ns_kernel: a world that finished last tick does not
+            // move this tick, it is re-seeded instead; any other marker waits
+            bool pending = false;
+            if (a.auto_reset == AQUA_RESET_NEXT_STEP) {
+                if (e.t == restart_code(tick - 1)) e.t = 0;
+                const bool restart = valid && e.t == done_code(tick - 1);
+                pending = valid && e.t < 0;
+                if (__any(restart)) {
+                    wave_reseed(e, restart, a, k, tick, wbase);
+                    if (restart) e.t = restart_code(tick);
+                }
+            }
             int idx = 2;
             float vl = 0.5f, vr = 0.5f;
             if constexpr (AK == AQUA_ACT_U8) idx = fold_index(static_cast<const uint8_t*>(a.action)[s * a.action_step_stride + ic]);
@@ -735,7 +926,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
             }
             const bool done = valid && code != 0u;
             if (a.auto_reset == AQUA_RESET_SAME_STEP) { if (__any(done)) wave_reseed(e, done, a, k, tick, wbase); }
-            else if (a.auto_reset == AQUA_RESET_NEXT_STEP && done) e.t = -1;
+            else if (a.auto_reset == AQUA_RESET_NEXT_STEP && done) e.t = done_code(tick);
         }
         if (valid) {
             a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
@@ -751,7 +942,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, co
 {
     AQUA_OBST_DECL
     const ObstPtr obst = stage_obstacles(s_obst, a.obst_blob, a.K);
-    const uint64_t tick = a.tick + (a.tick_base ? *a.tick_base : 0ull);
+    const uint64_t tick = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
          i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
@@ -808,7 +999,7 @@ int fill_args(StepArgs& a, const AquaParams* p, const void* blob, int K, int64_t
     if (!aligned(state, 4) || !aligned(time, 4)) return fail(AQUA_E_ALIGN, "state/time must be 4-byte aligned");
     if (env_offset < 0) return fail(AQUA_E_INVALID, "env_offset < 0");
     std::memset(&a, 0, sizeof(a));
-    a.state = state; a.ld = ld; a.time = time; a.obst_blob = blob; a.tick_base = tick_base;
+    a.state = state; a.ld = ld; a.time = time; a.obst_blob = K > 0 ? blob : nullptr; a.tick_base = tick_base;
     a.seed = seed; a.tick = tick; a.N = N; a.env_offset = env_offset; a.K = K;
     a.waves = p->waves; a.time_limit = p->time_limit;
     a.random_boat = p->random_boat; a.random_goal = p->random_goal;
@@ -867,9 +1058,11 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_step_ns(const StepArgs& a, int kind, hipStream_t s)
+hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
 {
-    const int64_t tiles = (a.N + NS_TILE - 1) / NS_TILE;
+    StepArgs a = a0;
+    a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
+    const int64_t tiles = (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     if (tiles > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
     switch (kind) {
@@ -1035,6 +1228,39 @@ int aqua_debug_reseed_bench(const AquaParams* p, const void* blob, int K, unsign
     hipLaunchKernelGGL(reseed_bench_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a, out_dev, 200);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "reseed bench");
+}
+
+// Launch skeletons for tools/skeleton.py: what a launch of the step's shape costs with (kind 0) an empty
+// body, (kind 1) the step's memory traffic only (8 rows + 1 byte in, 6 rows + 1 float + 1 byte out per world),
+// (kind 2) kind 1 with `spin` dependent FMAs per lane between the loads and the stores.
+__global__ void __launch_bounds__(512) skeleton_kernel(int kind, float* buf, int64_t ld, int64_t n, int spin)
+{
+    if (kind == 0) return;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = buf[j * ld + i];
+    const uint8_t act = reinterpret_cast<const uint8_t*>(buf + 8 * ld)[i];
+    float acc = v[0] + act;
+    for (int s = 0; s < spin; ++s) acc = fmaf(acc, 1.0000001f, v[1]);
+    v[0] = acc;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st1(buf + j * ld + i, v[j] + 1.0f);
+#pragma unroll
+    for (int j = 5; j < 8; ++j) st1(buf + j * ld + i, v[j] + 1.0f);
+    st1(buf + 9 * ld + i, v[3] + v[4]);
+    st1(reinterpret_cast<uint8_t*>(buf + 10 * ld) + i, static_cast<uint8_t>(act + 1));
+}
+
+int aqua_debug_skeleton(int kind, int block, float* buf, int64_t ld, int64_t n, int spin, void* stream)
+{
+    if (block < 64 || block > 512) return fail(AQUA_E_INVALID, "block must be 64..512");
+    const int64_t grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(skeleton_kernel, dim3(static_cast<unsigned>(grid)), dim3(block), 0, static_cast<hipStream_t>(stream),
+                       kind, buf, ld, n, spin);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "skeleton");
 }
 
 int aqua_debug_set_stamps(unsigned long long* dev_ptr)

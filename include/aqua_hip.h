@@ -108,9 +108,13 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
  *                   aqua_reset_f32(mask = term != 0) would; reward/term/done_bits still describe the step
  *                   that finished; the observation is already the new episode's.
  *                   AQUA_RESET_NEXT_STEP -> (Gymnasium >= 1.0 convention, the fastest mode) a world that finishes
- *                   at tick t keeps its terminal state, time[i] = -1 marks it, and the launch of tick t + 1
+ *                   at tick t keeps its terminal state and is marked in time[]; the launch of tick t + 1
  *                   re-initialises it instead of stepping it: that tick reports the fresh observation with
- *                   reward 0 and term 0.
+ *                   reward 0 and term 0.  Negative time[] values are this bookkeeping, tagged with the parity of
+ *                   the tick that wrote them (which is what lets the re-initialisation run beside the stepping
+ *                   inside one launch without any synchronisation): -1 - (t & 1) "finished at tick t, awaiting
+ *                   restart", -3 - (t & 1) "restarted during tick t, steps from time 0 at tick t + 1".  Ticks must
+ *                   advance by one per step in this mode (a marked world otherwise waits one extra step).
  */
 int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
                   float* state, int64_t ld, int32_t* time, const void* action, int action_kind,

@@ -362,12 +362,22 @@ int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves,
     int64_t episodes = 0, c1 = 0, c2 = 0, c3 = 0;
     for (int64_t t = 0; t < steps; ++t) {
         uint64_t tick = tick0 + (uint64_t)t;
-        /* auto_reset == 2 ("next-step"): worlds marked pending (time == -1) at the start of the tick do not
-         * step; they are re-initialised during this tick and report reward 0, term 0 */
+        /* auto_reset == 2 ("next-step").  Markers in the time row, with the parity of the tick that wrote them:
+         *   -1 - (t & 1)  finished at tick t, waits for its restart;  -3 - (t & 1)  restarted during tick t.
+         * At this tick: worlds marked "finished at tick - 1" are re-initialised and marked "restarted at tick";
+         * worlds marked "restarted at tick - 1" step from time 0; every other marker does not move.  Marked
+         * worlds that do not step report reward 0, term 0. */
         uint8_t* pending = NULL;
+        uint8_t* restart = NULL;
         if (auto_reset == 2) {
+            const int32_t fresh = -3 - (int32_t)((tick - 1) & 1u), finished = -1 - (int32_t)((tick - 1) & 1u);
             pending = (uint8_t*)malloc((size_t)n);
-            for (int64_t i = 0; i < n; ++i) pending[i] = time[i] < 0;
+            restart = (uint8_t*)malloc((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                if (time[i] == fresh) time[i] = 0;
+                restart[i] = time[i] == finished;
+                pending[i] = time[i] < 0;
+            }
         }
 #pragma omp parallel for schedule(static) reduction(+ : episodes, c1, c2, c3)
         for (int64_t i = 0; i < n; ++i) {
@@ -397,14 +407,19 @@ int64_t aqua_oracle_rollout_f32(int64_t n, int K, const double* obst, int waves,
             term[i] = code;
             if (code) { episodes++; c1 += code == 1; c2 += code == 2; c3 += code == 3; }
             if (code && auto_reset == 2) {
-                time[i] = -1;                           /* pending: goal stays, pose/wave are the terminal ones */
+                /* pending: goal stays, pose/wave are the terminal ones.  The marker carries the parity of the
+                 * tick that finished the world (-1 even, -2 odd), as the device writes it. */
+                time[i] = -1 - (int32_t)(tick & 1u);
             }
         }
         if (auto_reset == 1)
             aqua_oracle_reset(n, K, obst, waves, 1, 1, seed, tick, env_offset, term, state, ld, time);
         if (auto_reset == 2) {
-            aqua_oracle_reset(n, K, obst, waves, 1, 1, seed, tick, env_offset, pending, state, ld, time);
+            aqua_oracle_reset(n, K, obst, waves, 1, 1, seed, tick, env_offset, restart, state, ld, time);
+            for (int64_t i = 0; i < n; ++i)
+                if (restart[i]) time[i] = -3 - (int32_t)(tick & 1u);
             free(pending);
+            free(restart);
         }
     }
     if (term_counts) { term_counts[0] = c1; term_counts[1] = c2; term_counts[2] = c3; }

@@ -169,7 +169,7 @@ def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
     """device-sampled actions + restart of finished worlds, 40 steps, against the oracle's float32-state
     rollout: teacher-forced per step (the oracle restarts from the kernel's state every step).
     mode 1: finished worlds are re-seeded in the launch that finished them; mode 2 (next-step): they are
-    marked pending (time == -1) and re-seeded during the next step, which reports reward 0 / term 0."""
+    marked pending (time == -1 - (tick & 1)) and re-seeded during the next step, which reports reward 0 / term 0."""
     from aquaticgymenv_amd import presets
     n = 8192 + 37
     for continuous in (False, True):
@@ -192,12 +192,13 @@ def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
             assert np.max(np.abs(rew_h - o_rew)) <= TOL
             assert np.array_equal(k_time, tt)
             assert np.array_equal(env.done_mask().cpu().numpy(), (o_term != 0).astype(np.uint8))
-            reseeded = (o_term != 0) if mode == 1 else (t0 < 0)
+            reseeded = (o_term != 0) if mode == 1 else (t0 == -1 - ((tick - 1) & 1))
             # worlds that restarted: float32 reset specification, bit for bit
             assert np.array_equal(k_state[:, reseeded], st[:, reseeded])
             if mode == 2:
-                assert np.all(rew_h[reseeded] == 0) and np.all(term_h[reseeded] == 0) and np.all(k_time[reseeded] == 0)
-                assert np.all(k_time[o_term != 0] == -1)
+                assert np.all(rew_h[reseeded] == 0) and np.all(term_h[reseeded] == 0)
+                assert np.all(k_time[reseeded] == -3 - (tick & 1))        # restarted this tick, steps from 0 next tick
+                assert np.all(k_time[o_term != 0] == -1 - (tick & 1))     # marker carries the finishing tick's parity
             live = ~reseeded
             assert np.max(np.abs(k_state[0:2, live] - st[0:2, live])) <= TOL
             assert np.max(angle_diff(k_state[2, live], st[2, live])) <= TOL
