@@ -68,7 +68,7 @@ struct StepConst {              // wave-uniform
     int time_limit;             // aqua.py:91
     int K, Kc;                  // obstacles, of which the first Kc are circles
     float band2, band2_tight;
-    uint32_t touch;             // OR of one word per table cache line (see make_const): a dependency, not data
+    uint32_t touch[4];          // one word per table cache line (see make_const): dependencies, not data
     ObstPtr obst;               // float32 table (scalar-loaded from the blob, or the LDS copy)
     const double* obst64;       // global float64 rows [K][5] (exact path)
 };

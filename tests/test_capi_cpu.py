@@ -50,6 +50,7 @@ def test_pack_obstacles_layout(capi):
     blob = capi.pack_obstacles(presets.BENCH8)
     k = 8
     assert len(blob) == capi.lib.aqua_obstacle_blob_bytes(k) == 32 + k * 32 + k * 40
+    assert capi.lib.aqua_obstacle_blob_bytes(1) == 320       # never shorter than the five cache lines the kernels touch
     hdr_i = np.frombuffer(blob[:8], dtype=np.int32)
     hdr_f = np.frombuffer(blob[8:16], dtype=np.float32)
     assert hdr_i.tolist() == [8, 4]                       # 8 obstacles, 4 circles first
@@ -57,11 +58,11 @@ def test_pack_obstacles_layout(capi):
     rows = np.frombuffer(blob[32:32 + k * 32], dtype=np.float32).reshape(k, 8)
     assert np.all(rows[:4, 2:4] == 0) and np.all(rows[4:, 2:4] > 0)        # circles have no half extents
     assert np.allclose(rows[:4, 4], (presets.BENCH8[:4, 3] + 2.5) ** 2) and np.all(rows[4:, 4] == 6.25)
-    f64 = np.frombuffer(blob[32 + k * 32:], dtype=np.float64).reshape(k, 5)
+    f64 = np.frombuffer(blob[32 + k * 32:32 + k * 72], dtype=np.float64).reshape(k, 5)
     assert np.array_equal(f64, presets.BENCH8)            # BENCH8 is already circles-first
     mixed = presets.DEFAULT5                              # c c r c c -> c c c c r
     b2 = capi.pack_obstacles(mixed)
-    f64 = np.frombuffer(b2[32 + 5 * 32:], dtype=np.float64).reshape(5, 5)
+    f64 = np.frombuffer(b2[32 + 5 * 32:32 + 5 * 72], dtype=np.float64).reshape(5, 5)
     assert f64[:, 2].tolist() == [0, 0, 0, 0, 1]
     assert sorted(map(tuple, f64.tolist())) == sorted(map(tuple, mixed.tolist()))
     assert capi.pack_obstacles(presets.NONE) == b""
