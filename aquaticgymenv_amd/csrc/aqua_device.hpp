@@ -537,9 +537,15 @@ __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t
 #else
 #define AQUA_RESEED_ATTR __noinline__
 #endif
-template <int G>
+// ROWS: the table (ROWS rows, absent ones with r2 < 0) is read from `rows` in LDS, four rows at a time, instead
+// of through the scalar path, which waits once per two rows.
+#ifndef AQUA_RESEED_HALF_BARRIER
+#define AQUA_RESEED_HALF_BARRIER 1
+#endif
+template <int G, int ROWS = 0>
 __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
-                                                     int random_boat, int random_goal, int K, ObstPtr t)
+                                                     int random_boat, int random_goal, int K, ObstPtr t,
+                                                     const ObstF* rows = nullptr)
 {
 #pragma clang fp contract(off)
     static_assert(G >= 2 && G <= 64 && (G & (G - 1)) == 0, "group size");
@@ -568,9 +574,7 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
 #ifndef AQUA_RESEED_UNROLL
 #define AQUA_RESEED_UNROLL 2
 #endif
-#pragma unroll AQUA_RESEED_UNROLL
-        for (int j = 0; j < K; ++j) {
-            const float cx = t[j].cx, cy = t[j].cy, hx = t[j].hx, hy = t[j].hy, r2 = t[j].r2;
+        auto test = [&](float cx, float cy, float hx, float hy, float r2) {
             const float gax = fabsf(cgx - cx), gay = fabsf(cgy - cy);
             const float gdx = fmaxf(gax - hx, 0.0f), gdy = fmaxf(gay - hy, 0.0f);
             const float gdy2 = gdy * gdy;
@@ -579,6 +583,37 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
             const float bdx = fmaxf(bax - hx, 0.0f), bdy = fmaxf(bay - hy, 0.0f);
             const float bdy2 = bdy * bdy;
             hit_b |= fmaf(bdx, bdx, bdy2) <= r2;
+        };
+        if constexpr (ROWS > 0) {                        // `rows` is in LDS: a few rows in registers at a time
+#ifndef AQUA_RESEED_ROWS_PER_STEP
+#define AQUA_RESEED_ROWS_PER_STEP 2
+#endif
+            constexpr int RS = AQUA_RESEED_ROWS_PER_STEP;
+#pragma unroll
+            for (int h = 0; h < ROWS; h += RS) {
+                // (the index is laundered so that the reads stay here, next to their use, instead of being
+                // hoisted out of the attempt loop into forty long-lived registers)
+                int first_row = h;
+                asm volatile("" : "+v"(first_row));
+                const ObstF* r = rows + first_row;
+                float c[RS][5];
+#pragma unroll
+                for (int j = 0; j < RS; ++j) {
+                    c[j][0] = r[j].cx; c[j][1] = r[j].cy; c[j][2] = r[j].hx; c[j][3] = r[j].hy; c[j][4] = r[j].r2;
+                }
+#pragma unroll
+                for (int j = 0; j < RS; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
+#if AQUA_RESEED_HALF_BARRIER
+                // finish these rows before the next ones are read: without it the vectoriser pairs operations
+                // across ALL rows and keeps the whole table (and sixteen partial results) live at once
+                uint32_t fg = hit_g, fb = hit_b;
+                asm volatile("" : "+v"(fg), "+v"(fb));
+                hit_g = fg != 0u; hit_b = fb != 0u;
+#endif
+            }
+        } else {
+#pragma unroll AQUA_RESEED_UNROLL
+            for (int j = 0; j < K; ++j) test(t[j].cx, t[j].cy, t[j].hx, t[j].hy, t[j].r2);
         }
         // goal: lowest accepted attempt of the group (aqua.py:103-105)
         const uint64_t gm = (__ballot(!goal_found && !hit_g) >> gbase) & gmask;

@@ -187,16 +187,17 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
     k.obst = obst;
     k.Kc = 0; k.band2 = 0.0f; k.band2_tight = 0.0f;
     k.touch[0] = k.touch[1] = k.touch[2] = k.touch[3] = 0;
-#ifdef AQUA_EXP_NO_DEREF
-    if (a.K > 0) { k.Kc = 4; k.band2 = 3.1e-3f; k.band2_tight = 2.0e-4f; }   // timing experiment only
-    else
-#endif
     if (a.obst_blob != nullptr) {        // header fields: uniform scalar loads (the pointer is NULL when K == 0)
         const ObstHeader __attribute__((address_space(4)))* h =
             (const ObstHeader __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
+#ifdef AQUA_EXP_NO_DEREF                 // timing experiment only: header by value (BENCH8's), tick by value
+        k.Kc = 4; k.band2 = 3.1e-3f; k.band2_tight = 2.0e-4f;
+        (void)h;
+#else
         k.Kc = h->n_circles;
         k.band2 = h->band2;
         k.band2_tight = h->band2_tight;
+#endif
         // Touch the table's cache lines now (rows 2l - 1 and 2l share line l; row 0 shares the header's): the
         // scalar cache starts every launch cold, and the row loads of the obstacle passes are issued two rows
         // at a time -- each of them would otherwise be a miss of its own, one memory round trip after the other.
@@ -650,7 +651,12 @@ static_assert(NS_SCAN <= 65536, "list entries are 16-bit offsets");
 __device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static_cast<int32_t>(tick & 1u); }
 __device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
 
+#ifndef AQUA_NS_TABLE_ROWS
+#define AQUA_NS_TABLE_ROWS 8
+#endif
+constexpr int NS_TABLE_ROWS = AQUA_NS_TABLE_ROWS;   // tables of up to this many obstacles are staged in LDS for the re-seeding pass (0: never)
 struct NsReseedShared {
+    ObstF rows[NS_TABLE_ROWS > 0 ? NS_TABLE_ROWS : 1];
     uint32_t count[NS_MAIN_WAVES];
     uint16_t list[NS_MAIN_WAVES][NS_SCAN_ROWS * 64];
 };
@@ -673,6 +679,13 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
         tw[j] = ld1(trow + (i < last ? i : last));
     }
+    // Small tables (the usual case) are copied into LDS by the first lanes -- one vector load each, in flight with
+    // the time row -- and the obstacle pass of the re-seeding reads them from there after the barrier below,
+    // four rows per wait (through the scalar path it waits once per two rows, 200 clocks each).
+    const bool table_in_regs = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;    // uniform
+    uint32_t table_word = 0;
+    if (table_in_regs && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
+        table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
     const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick = launch_tick(a);
     const int32_t restart = done_code(tick - 1);
@@ -693,7 +706,13 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         n_mine += static_cast<uint32_t>(__builtin_popcountll(m));
     }
     if (lane == 0) sh.count[wave] = n_mine;
+    if (table_in_regs && threadIdx.x < NS_TABLE_ROWS * 8) {
+        // absent rows: r2 = -3e38, which no squared distance is ever below (word 4 of a row is r2)
+        const bool present = threadIdx.x < static_cast<uint32_t>(a.K) * 8;
+        reinterpret_cast<uint32_t*>(sh.rows)[threadIdx.x] = present ? table_word : ((threadIdx.x & 7u) == 4u ? 0xFF61B1E6u : 0u);
+    }
     __syncthreads();
+
     uint32_t first[NS_MAIN_WAVES + 1];
     first[0] = 0;
 #pragma unroll
@@ -709,8 +728,15 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
 #pragma unroll
         for (int w = 1; w < NS_MAIN_WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
         const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
-        const EnvState e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + base) + i, tick,
-                                                            k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        const uint64_t env = static_cast<uint64_t>(a.env_offset + base) + i;
+        EnvState e;
+        if constexpr (NS_TABLE_ROWS > 0) {
+            e = table_in_regs
+                ? reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows)
+                : reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        } else {
+            e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        }
         if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
             st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
             st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -798,7 +824,11 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     AQUA_RTSTAMP(4);        // draws done, loads back
     fold_actions<1, AK>(araw, aidx);
     const int32_t t0 = tin[0] == restart_code(tick - 1) ? 0 : tin[0];   // restarted last tick: steps from 0
+#ifdef AQUA_NS_NOWORK
+    const bool pending = false;                        // (timing experiment: nobody restarts, every world keeps stepping)
+#else
     const bool pending = valid && t0 < 0;              // any other marker: the world does not step
+#endif
     if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
     EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
@@ -830,7 +860,11 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     if (live) {                                        // pending worlds are written by the re-seeding blocks
         st1(row0 + 0 * ld + off, e.x); st1(row0 + 1 * ld + off, e.y); st1(row0 + 2 * ld + off, e.th);
         st1(row0 + 5 * ld + off, e.wx); st1(row0 + 6 * ld + off, e.wy);
+#ifdef AQUA_NS_NOWORK
+        st1(trow + off, e.t);
+#else
         st1(trow + off, done ? done_code(tick) : e.t);
+#endif
         write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
     }
     AQUA_RTSTAMP(2);
