@@ -17,7 +17,7 @@ SYMBOLS = (
     "aqua_version", "aqua_last_error", "aqua_obstacle_blob_bytes", "aqua_pack_obstacles", "aqua_step_f32",
     "aqua_reset_f32", "aqua_rollout_f32", "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin",
     "aqua_graph_end", "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width",
-    "aqua_discrete_constants", "aqua_set_vector_width",
+    "aqua_discrete_constants", "aqua_set_vector_width", "aqua_obs_norm_f32",
 )
 
 
@@ -55,6 +55,7 @@ def _load():
     lib.aqua_rollout_fused_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp,
                                            vp, vp, i64, ci, vp]
     lib.aqua_tick_advance.argtypes = [vp, u64, vp]
+    lib.aqua_obs_norm_f32.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.aqua_graph_begin.argtypes = [vp]
     lib.aqua_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
     lib.aqua_graph_launch.argtypes = [vp, vp]
@@ -65,7 +66,8 @@ def _load():
     lib.aqua_set_vector_width.argtypes = [ci]
     for name in ("aqua_pack_obstacles", "aqua_step_f32", "aqua_reset_f32", "aqua_rollout_f32",
                  "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin", "aqua_graph_end",
-                 "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width", "aqua_set_vector_width"):
+                 "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width", "aqua_set_vector_width",
+                 "aqua_obs_norm_f32"):
         getattr(lib, name).restype = ci
     if lib.aqua_version() != ABI_VERSION:
         raise ImportError("libaqua_hip.so ABI %d != binding %d: rebuild" % (lib.aqua_version(), ABI_VERSION))

@@ -199,6 +199,9 @@ class BatchedAqua(object):
             _capi.check(_capi.lib.aqua_reset_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
                                                  self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
                                                  mptr, self.seed, self._tick, None, self._stream()), "aqua_reset_f32")
+            if self._norm_ptr() is not None:          # the step kernels' epilogue, for the worlds just placed
+                _capi.check(_capi.lib.aqua_obs_norm_f32(self.state.data_ptr(), self.ld, self.num_envs, mptr,
+                                                        self._norm_ptr(), self._stream()), "aqua_obs_norm_f32")
         self._tick += 1
         return self.obs
 

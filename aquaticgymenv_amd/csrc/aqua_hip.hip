@@ -1002,6 +1002,20 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, co
 
 __global__ void tick_kernel(uint64_t* tick_base, uint64_t delta) { *tick_base += delta; }
 
+__global__ __launch_bounds__(BLOCK_SMALL) void obs_norm_kernel(const float* __restrict__ state, int64_t ld, int64_t N,
+                                                               const uint8_t* __restrict__ mask, float* __restrict__ out)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
+         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+        if (mask != nullptr && mask[i] == 0) continue;
+        out[0 * ld + i] = state[0 * ld + i] * 0.01f;
+        out[1 * ld + i] = state[1 * ld + i] * 0.01f;
+        out[2 * ld + i] = fmaf(state[2 * ld + i], 0.15915494309189535f, 0.5f);
+        out[3 * ld + i] = state[3 * ld + i] * 0.01f;
+        out[4 * ld + i] = state[4 * ld + i] * 0.01f;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 thread_local char g_err[512] = "";
 std::atomic<int> g_vec_override{0};
@@ -1414,6 +1428,18 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_rollout_fused_f32 launch");
+}
+
+int aqua_obs_norm_f32(const float* state, int64_t ld, int64_t N, const uint8_t* mask, float* obs_norm, void* stream)
+{
+    if (N < 0 || ld < N) return fail(AQUA_E_INVALID, "bad sizes: N=%lld ld=%lld", (long long)N, (long long)ld);
+    if (N == 0) return 0;
+    if (state == nullptr || obs_norm == nullptr) return fail(AQUA_E_INVALID, "state/obs_norm is NULL");
+    if (!aligned(state, 4) || !aligned(obs_norm, 4)) return fail(AQUA_E_ALIGN, "state/obs_norm must be 4-byte aligned");
+    hipLaunchKernelGGL(obs_norm_kernel, dim3(grid_for(N, BLOCK_SMALL, 2048)), dim3(BLOCK_SMALL), 0,
+                       static_cast<hipStream_t>(stream), state, ld, N, mask, obs_norm);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "aqua_obs_norm_f32 launch");
 }
 
 int aqua_tick_advance(uint64_t* tick_base_dev, uint64_t delta, void* stream)

@@ -155,6 +155,13 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
                            uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
                            int64_t out_step_stride, int auto_reset, void* stream);
 
+/*
+ * obs_norm[5][ld] <- the observation of `state` scaled as the reference's AquaStateNormalizer
+ * (main/impl/utils.py:15-33): what the step kernels' obs_norm epilogue writes, for the worlds a reset just
+ * placed (mask as in aqua_reset_f32; NULL: all N).
+ */
+int aqua_obs_norm_f32(const float* state, int64_t ld, int64_t N, const uint8_t* mask, float* obs_norm, void* stream);
+
 /* *tick_base_dev += delta, as a 1-thread kernel on `stream` (the last node of a captured rollout graph). */
 int aqua_tick_advance(uint64_t* tick_base_dev, uint64_t delta, void* stream);
 

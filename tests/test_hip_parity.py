@@ -497,7 +497,8 @@ def test_trained_dqn_policies_reach_the_published_success_rates(torch, tag, obst
     policy = GreedyQPolicy(layers, "cuda:0")
     first = torch.zeros(n, dtype=torch.uint8, device="cuda")
     total = torch.zeros(n, dtype=torch.float32, device="cuda")
-    obs_norm = env.obs / scale + shift                 # after reset(); afterwards the kernels' fused epilogue supplies it
+    obs_norm = env.obs_norm                            # reset() and every step write it (AquaStateNormalizer)
+    assert float((obs_norm - (env.obs / scale + shift)).abs().max()) < 1e-6
     for step in range(1001):
         action = policy(obs_norm)
         obs, reward, term = env.step(action)
