@@ -105,8 +105,11 @@ class BatchedAqua(object):
             self._tick_dev = torch.zeros(1, dtype=torch.int64, device=dev)
             # optional fused epilogue (main/impl/utils.py:15-33): obs / (high - low), angle + 0.5
             self.obs_norm_buf = torch.zeros((5, self.ld), dtype=torch.float32, device=dev) if normalized_obs else None
-        self._tick = 0
+        self._tick = 0                    # one per step: draws of the step, and of the restarts the step kernels do
         self._device_tick = 0
+        self._resets = 0                  # one per reset() call: its draws use tick RESET_TICK_BASE + _resets, so
+                                          # that a reset between two steps does not shift the steps' tick parity
+                                          # (the next-step restart markers carry it, include/aqua_hip.h)
         self._action_soa = None           # staging for (N, 2) -> [2][ld] continuous actions
 
     # ------------------------------------------------------------------ plumbing
@@ -183,6 +186,8 @@ class BatchedAqua(object):
         return a, a.data_ptr(), kind, 0
 
     # ------------------------------------------------------------------ the path
+    RESET_TICK_BASE = 1 << 40             # reset() draws live far above any step tick
+
     def reset(self, mask=None):
         """(Re)start worlds: all of them, or those with mask[i] != 0 (uint8/bool tensor).  aqua.py:100-126."""
         torch = self.torch
@@ -198,11 +203,12 @@ class BatchedAqua(object):
         with torch.cuda.device(self.device):
             _capi.check(_capi.lib.aqua_reset_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
                                                  self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
-                                                 mptr, self.seed, self._tick, None, self._stream()), "aqua_reset_f32")
+                                                 mptr, self.seed, self.RESET_TICK_BASE + self._resets, None,
+                                                 self._stream()), "aqua_reset_f32")
             if self._norm_ptr() is not None:          # the step kernels' epilogue, for the worlds just placed
                 _capi.check(_capi.lib.aqua_obs_norm_f32(self.state.data_ptr(), self.ld, self.num_envs, mptr,
                                                         self._norm_ptr(), self._stream()), "aqua_obs_norm_f32")
-        self._tick += 1
+        self._resets += 1
         return self.obs
 
     def _device_policy(self, name):

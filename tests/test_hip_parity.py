@@ -208,6 +208,32 @@ def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
         assert finished > n // 4
 
 
+def test_masked_reset_between_steps_does_not_delay_restarts(torch):
+    """next-step mode: the restart markers carry the parity of the step tick; a reset(mask) between two steps
+    draws from its own tick range, so the worlds that finished in the step before it still restart in the step
+    after it (time == -3 - (tick & 1)), and the worlds it placed step normally."""
+    from aquaticgymenv_amd import presets
+    n = 20000
+    env = _make(torch, n, presets.BENCH8, seed=31, auto_reset="next_step")
+    env.reset()
+    for _ in range(30):
+        env.step(sample_actions=True)
+    obs, reward, term = env.step(sample_actions=True)
+    finished = (term != 0).cpu().numpy()
+    assert finished.sum() > 50
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[np.flatnonzero(~finished)[:100]] = 1
+    env.reset(mask=torch.as_tensor(mask).cuda())
+    tick = env._tick
+    obs, reward, term = env.step(sample_actions=True)
+    torch.cuda.synchronize()
+    t = env.time[:n].cpu().numpy()
+    assert np.all(t[finished] == -3 - (tick & 1))
+    assert np.all(reward.cpu().numpy()[finished] == 0) and np.all(term.cpu().numpy()[finished] == 0)
+    placed = mask != 0
+    assert np.all((t[placed] == 1) | (t[placed] == -1 - (tick & 1)))      # stepped once (or finished at once)
+
+
 # ------------------------------------------------------------------------------------------------
 # reset
 # ------------------------------------------------------------------------------------------------
@@ -222,7 +248,7 @@ def test_reset_bit_exact_vs_oracle_spec(torch, oracle, obst):
     k_state, k_time = _host_state(env)
     st = np.zeros((7, n), dtype=np.float32)
     tt = np.full(n, 5, dtype=np.int32)
-    oracle.reset(st, tt, obstacles=rows, waves=1, seed=4242, tick=0, env_offset=17)
+    oracle.reset(st, tt, obstacles=rows, waves=1, seed=4242, tick=env.RESET_TICK_BASE, env_offset=17)
     assert np.array_equal(k_state, st)
     assert np.array_equal(k_time, tt)
     # masked reset touches only the masked worlds
@@ -233,7 +259,7 @@ def test_reset_bit_exact_vs_oracle_spec(torch, oracle, obst):
     after, _ = _host_state(env)
     assert np.array_equal(after[:, ~mask], before[:, ~mask])
     assert not np.array_equal(after[:, mask], before[:, mask])
-    oracle.reset(st, tt, obstacles=rows, waves=1, seed=4242, tick=1, env_offset=17, mask=mask.astype(np.uint8))
+    oracle.reset(st, tt, obstacles=rows, waves=1, seed=4242, tick=env.RESET_TICK_BASE + 1, env_offset=17, mask=mask.astype(np.uint8))
     assert np.array_equal(after, st)
 
 
