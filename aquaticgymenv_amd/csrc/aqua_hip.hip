@@ -98,6 +98,19 @@ __device__ __forceinline__ void st1(T* p, T v)
 #endif
 }
 
+// uniform base + zero-extended 32-bit BYTE offset: the form the backend turns into `global_load v, voffset, s[base]`
+// (no 64-bit address arithmetic per lane)
+template <typename T>
+__device__ __forceinline__ T ld_at(const T* base, uint32_t byte_off)
+{
+    return ld1(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+template <typename T>
+__device__ __forceinline__ void st_at(T* base, uint32_t byte_off, T v)
+{
+    st1(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+}
+
 template <int VEC, bool FULL, typename T>
 __device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, int64_t rem, T (&v)[VEC])
 {
@@ -788,20 +801,17 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     int32_t tin[1];
     int64_t araw[1] = {2};
     int aidx[1] = {2};
-    tin[0] = ld1(trow + o);
-    x[0] = ld1(row0 + 0 * ld + o); y[0] = ld1(row0 + 1 * ld + o); th[0] = ld1(row0 + 2 * ld + o);
-    gx[0] = ld1(row0 + 3 * ld + o); gy[0] = ld1(row0 + 4 * ld + o);
-    wx[0] = ld1(row0 + 5 * ld + o); wy[0] = ld1(row0 + 6 * ld + o);
-    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld1(static_cast<const uint8_t*>(a.action) + tile + o);
-    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld1(static_cast<const int32_t*>(a.action) + tile + o);
-    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld1(static_cast<const int64_t*>(a.action) + tile + o);
+    const uint32_t o4 = o * 4u;                         // < 1024: lane byte offset inside a float/int row
+    tin[0] = ld_at(trow, o4);
+    x[0] = ld_at(row0 + 0 * ld, o4); y[0] = ld_at(row0 + 1 * ld, o4); th[0] = ld_at(row0 + 2 * ld, o4);
+    gx[0] = ld_at(row0 + 3 * ld, o4); gy[0] = ld_at(row0 + 4 * ld, o4);
+    wx[0] = ld_at(row0 + 5 * ld, o4); wy[0] = ld_at(row0 + 6 * ld, o4);
+    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action) + tile, o);
+    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action) + tile, o4);
+    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action) + tile, o * 8u);
     else if constexpr (AK == AQUA_ACT_F32X2) {
-        avl[0] = ld1(static_cast<const float*>(a.action) + tile + o);
-        avr[0] = ld1(static_cast<const float*>(a.action) + a.action_ld + tile + o);
-    }
-    if (a.noise != nullptr) {                          // injected noise (tests)
-        u0[0] = ld1(a.noise + tile + o);
-        u1[0] = ld1(a.noise + a.noise_ld + tile + o);
+        avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
+        avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
     }
     const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick = launch_tick(a);
@@ -812,6 +822,10 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         uint32_t w0[1], w1[1];
         pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
         u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
+    } else {                                           // injected noise (tests): loaded here, not up front, so that no
+        u0[0] = ld_at(a.noise + tile, o4);             // load of this rare path is outstanding across the draws
+        u1[0] = ld_at(a.noise + a.noise_ld + tile, o4);
+        asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));   // waited for right here: see above
     }
     if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
         uint32_t w0[1], w1[1];
@@ -849,8 +863,8 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
     const bool done = code != 0u;
     if (valid) {
-        st1(a.reward + tile + off, rew);
-        st1(a.term + tile + off, static_cast<uint8_t>(code));
+        st_at(a.reward + tile, o4, rew);
+        st_at(a.term + tile, o, static_cast<uint8_t>(code));
     }
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done);
@@ -858,12 +872,12 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
     }
     if (live) {                                        // pending worlds are written by the re-seeding blocks
-        st1(row0 + 0 * ld + off, e.x); st1(row0 + 1 * ld + off, e.y); st1(row0 + 2 * ld + off, e.th);
-        st1(row0 + 5 * ld + off, e.wx); st1(row0 + 6 * ld + off, e.wy);
+        st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
+        st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
 #ifdef AQUA_NS_NOWORK
-        st1(trow + off, e.t);
+        st_at(trow, o4, e.t);
 #else
-        st1(trow + off, done ? done_code(tick) : e.t);
+        st_at(trow, o4, done ? done_code(tick) : e.t);
 #endif
         write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
     }
