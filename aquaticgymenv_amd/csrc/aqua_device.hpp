@@ -432,7 +432,7 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
 
     bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
     float mc_f = mc, mo_f = mo, mg_f = mg;
-    if (__any(knife)) {
+    if (__builtin_expect(__any(knife) != 0, 0)) {
         // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
         // by the rounding of x' = x + ddx itself (up to 3.8e-6).  Carry the rounding error of that sum
         // (xlo = ddx - (x' - x), exact: FastTwoSum) through the three margins; what is left is the error of
@@ -638,7 +638,7 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
     }
     // goal attempts exhausted: the goal stays at its fixed default (aqua.py:107) and the boat is still scanned
     if (active && random_boat && !boat_done && !goal_found) serial = true;
-    if (__any(serial)) {
+    if (__builtin_expect(__any(serial) != 0, 0)) {
         if (serial && sub == 0) {
             uint32_t rr[4];
             for (uint32_t a = 0; a < RESET_TRIES; ++a) {

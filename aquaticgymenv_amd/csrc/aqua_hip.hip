@@ -674,6 +674,9 @@ struct NsReseedShared {
     uint16_t list[NS_MAIN_WAVES][NS_SCAN_ROWS * 64];
 };
 
+// SMALL_TABLE: the launch has at most NS_TABLE_ROWS obstacles (decided on the host: one kernel per case keeps the
+// code each launch has to fetch short -- the instruction cache starts every launch cold)
+template <bool SMALL_TABLE>
 __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block, ObstF* s_obst, NsReseedShared& sh)
 {
 #ifndef AQUA_NS_RESEED_PRIO
@@ -695,7 +698,7 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     // Small tables (the usual case) are copied into LDS by the first lanes -- one vector load each, in flight with
     // the time row -- and the obstacle pass of the re-seeding reads them from there after the barrier below,
     // four rows per wait (through the scalar path it waits once per two rows, 200 clocks each).
-    const bool table_in_regs = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;    // uniform
+    constexpr bool table_in_regs = SMALL_TABLE;
     uint32_t table_word = 0;
     if (table_in_regs && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
         table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
@@ -743,13 +746,10 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
         const uint64_t env = static_cast<uint64_t>(a.env_offset + base) + i;
         EnvState e;
-        if constexpr (NS_TABLE_ROWS > 0) {
-            e = table_in_regs
-                ? reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows)
-                : reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
-        } else {
+        if constexpr (SMALL_TABLE)
+            e = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
+        else
             e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
-        }
         if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
             st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
             st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -761,7 +761,7 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     AQUA_RTSTAMP(2);
 }
 
-template <int AK>
+template <int AK, bool SMALL_TABLE>
 __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     const int64_t role_index = reseed_role ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) - a.reseed_blocks;
     if (reseed_role) {
 #ifndef AQUA_NS_NOWORK                       // (timing experiment: what the re-seeding blocks cost the launch)
-        ns_reseed_block(a, role_index, s_obst, sh);
+        ns_reseed_block<SMALL_TABLE>(a, role_index, s_obst, sh);
 #endif
         return;
     }
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     AQUA_RTSTAMP(0);
     // The draws need no loaded value: they run in the shadow of the loads.
     const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
-    if (a.noise == nullptr) {
+    if (__builtin_expect(a.noise == nullptr, 1)) {
         uint32_t w0[1], w1[1];
         pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
         u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     AQUA_RTSTAMP(1);
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
     const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
-    if (__any(knife)) {
+    if (__builtin_expect(__any(knife) != 0, 0)) {
         if (knife) {
             const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
                                            k.obst, k.band2, k.time_limit);
@@ -1137,16 +1137,23 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     const int64_t tiles = (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     if (tiles > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
+    const bool small = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;
+#define AQUA_NS_LAUNCH(AK)                                                                           \
+    case AK:                                                                                         \
+        if (small) hipLaunchKernelGGL((step_ns_kernel<AK, true>), grid, block, 0, s, a);             \
+        else hipLaunchKernelGGL((step_ns_kernel<AK, false>), grid, block, 0, s, a);                  \
+        break;
     switch (kind) {
-        case AQUA_ACT_U8: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_U8>), grid, block, 0, s, a); break;
-        case AQUA_ACT_I32: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_I32>), grid, block, 0, s, a); break;
-        case AQUA_ACT_I64: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_I64>), grid, block, 0, s, a); break;
-        case AQUA_ACT_F32X2: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
-        case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
-        case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
-        case AQUA_ACT_BEARING: hipLaunchKernelGGL((step_ns_kernel<AQUA_ACT_BEARING>), grid, block, 0, s, a); break;
+        AQUA_NS_LAUNCH(AQUA_ACT_U8)
+        AQUA_NS_LAUNCH(AQUA_ACT_I32)
+        AQUA_NS_LAUNCH(AQUA_ACT_I64)
+        AQUA_NS_LAUNCH(AQUA_ACT_F32X2)
+        AQUA_NS_LAUNCH(AQUA_ACT_SAMPLE_D)
+        AQUA_NS_LAUNCH(AQUA_ACT_SAMPLE_C)
+        AQUA_NS_LAUNCH(AQUA_ACT_BEARING)
         default: return hipErrorInvalidValue;
     }
+#undef AQUA_NS_LAUNCH
     return hipGetLastError();
 }
 
