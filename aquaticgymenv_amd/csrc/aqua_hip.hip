@@ -1016,6 +1016,21 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, co
 
 __global__ void tick_kernel(uint64_t* tick_base, uint64_t delta) { *tick_base += delta; }
 
+// ring[r][(cursor + i) % capacity] = src[r][i]: the batch lands in consecutive slots, so both sides are coalesced
+// (the wrap splits at most one wavefront's store)
+template <typename T>
+__global__ __launch_bounds__(BLOCK_SMALL) void ring_write_kernel(T* __restrict__ ring, int64_t ring_ld, int64_t capacity,
+                                                                 int64_t cursor, const T* __restrict__ src, int64_t src_ld,
+                                                                 int rows, int64_t N)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
+         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+        int64_t slot = cursor + i;                       // cursor < capacity, i < N <= capacity
+        if (slot >= capacity) slot -= capacity;
+        for (int r = 0; r < rows; ++r) ring[r * ring_ld + slot] = src[r * src_ld + i];
+    }
+}
+
 __global__ __launch_bounds__(BLOCK_SMALL) void obs_norm_kernel(const float* __restrict__ state, int64_t ld, int64_t N,
                                                                const uint8_t* __restrict__ mask, float* __restrict__ out)
 {
@@ -1179,6 +1194,23 @@ int check_step_buffers(int64_t N, const void* action, int action_kind, int64_t a
     if (N > 0 && (reward == nullptr || term == nullptr)) return fail(AQUA_E_INVALID, "reward/term is NULL");
     if (!aligned(reward, 4)) return fail(AQUA_E_ALIGN, "reward must be 4-byte aligned");
     return 0;
+}
+
+template <typename T>
+int ring_write(T* ring, int64_t ring_ld, int64_t capacity, int64_t cursor, const T* src, int64_t src_ld, int rows, int64_t N,
+               void* stream)
+{
+    if (capacity <= 0 || ring_ld < capacity) return fail(AQUA_E_INVALID, "bad ring: capacity=%lld ring_ld=%lld", (long long)capacity, (long long)ring_ld);
+    if (N < 0 || N > capacity || src_ld < N) return fail(AQUA_E_INVALID, "bad sizes: N=%lld capacity=%lld src_ld=%lld", (long long)N, (long long)capacity, (long long)src_ld);
+    if (cursor < 0 || cursor >= capacity) return fail(AQUA_E_INVALID, "cursor %lld outside [0, capacity)", (long long)cursor);
+    if (rows < 0 || rows > 64) return fail(AQUA_E_INVALID, "rows=%d outside [0, 64]", rows);
+    if (N == 0 || rows == 0) return 0;
+    if (ring == nullptr || src == nullptr) return fail(AQUA_E_INVALID, "ring/src is NULL");
+    if (!aligned(ring, sizeof(T)) || !aligned(src, sizeof(T))) return fail(AQUA_E_ALIGN, "ring/src not aligned to the element size");
+    hipLaunchKernelGGL((ring_write_kernel<T>), dim3(grid_for(N, BLOCK_SMALL, 4096)), dim3(BLOCK_SMALL), 0,
+                       static_cast<hipStream_t>(stream), ring, ring_ld, capacity, cursor, src, src_ld, rows, N);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "aqua_ring_write launch");
 }
 
 }  // namespace
@@ -1461,6 +1493,18 @@ int aqua_obs_norm_f32(const float* state, int64_t ld, int64_t N, const uint8_t* 
                        static_cast<hipStream_t>(stream), state, ld, N, mask, obs_norm);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_obs_norm_f32 launch");
+}
+
+int aqua_ring_write_f32(float* ring, int64_t ring_ld, int64_t capacity, int64_t cursor, const float* src, int64_t src_ld,
+                        int rows, int64_t N, void* stream)
+{
+    return ring_write<float>(ring, ring_ld, capacity, cursor, src, src_ld, rows, N, stream);
+}
+
+int aqua_ring_write_u8(uint8_t* ring, int64_t ring_ld, int64_t capacity, int64_t cursor, const uint8_t* src,
+                       int64_t src_ld, int rows, int64_t N, void* stream)
+{
+    return ring_write<uint8_t>(ring, ring_ld, capacity, cursor, src, src_ld, rows, N, stream);
 }
 
 int aqua_tick_advance(uint64_t* tick_base_dev, uint64_t delta, void* stream)

@@ -162,6 +162,18 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
  */
 int aqua_obs_norm_f32(const float* state, int64_t ld, int64_t N, const uint8_t* mask, float* obs_norm, void* stream);
 
+/*
+ * Device-side replay ring (the experience buffer of main/impl/dqn.py:174, `exp_buffer.append([s, a, r, s', d])`,
+ * for a batch of worlds): ring[r][(cursor + i) % capacity] = src[r][i] for r < rows, i < N.  Rows are
+ * float32 (aqua_ring_write_f32) or bytes (aqua_ring_write_u8); `ring_ld`/`src_ld` are the row pitches in
+ * elements (ring_ld >= capacity).  Coalesced on both sides; N <= capacity.  A batched step is recorded as two
+ * calls around aqua_step_f32 into the same slots -- (s, a) before it, (r, s', d) after it.
+ */
+int aqua_ring_write_f32(float* ring, int64_t ring_ld, int64_t capacity, int64_t cursor, const float* src, int64_t src_ld,
+                        int rows, int64_t N, void* stream);
+int aqua_ring_write_u8(uint8_t* ring, int64_t ring_ld, int64_t capacity, int64_t cursor, const uint8_t* src,
+                       int64_t src_ld, int rows, int64_t N, void* stream);
+
 /* *tick_base_dev += delta, as a 1-thread kernel on `stream` (the last node of a captured rollout graph). */
 int aqua_tick_advance(uint64_t* tick_base_dev, uint64_t delta, void* stream);
 

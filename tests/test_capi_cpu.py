@@ -72,6 +72,18 @@ def test_pack_obstacles_layout(capi):
         capi.pack_obstacles(np.zeros((65, 5)))
 
 
+def test_ring_write_validation_without_touching_a_device(capi):
+    lib = capi.lib
+    buf = (ctypes.c_float * 64)()
+    addr = ctypes.addressof(buf)
+    assert lib.aqua_ring_write_f32(addr, 64, 64, 0, addr, 64, 5, 0, None) == 0          # N = 0: nothing to do
+    assert lib.aqua_ring_write_f32(addr, 64, 64, 64, addr, 64, 1, 8, None) == -1        # cursor outside the ring
+    assert lib.aqua_ring_write_f32(addr, 32, 64, 0, addr, 64, 1, 8, None) == -1         # pitch < capacity
+    assert lib.aqua_ring_write_u8(addr, 64, 64, 0, addr, 64, 1, 65, None) == -1         # batch larger than the ring
+    assert lib.aqua_ring_write_u8(None, 64, 64, 0, addr, 64, 1, 8, None) == -1
+    assert b"NULL" in lib.aqua_last_error()
+
+
 def test_argument_validation_without_touching_a_device(capi):
     lib = capi.lib
     p = capi.AquaParams(waves=1, time_limit=1000, random_boat=1, random_goal=1)
