@@ -1,15 +1,29 @@
 // aqua_hip.hip -- kernels and C ABI (include/aqua_hip.h) of the batched AquaEnv hot path, gfx950 only.
 //
-// Kernels
-//   step_kernel<VEC, AK>   one fused launch per batched step (reference: AquaEnv.step,
-//                          gym_aqua/envs/aqua.py:135-213).  One lane advances VEC consecutive worlds
-//                          (16-byte coalesced loads/stores on the SoA rows when VEC == 4), the obstacle
-//                          table is staged into LDS once per workgroup, done flags are packed with
-//                          wavefront ballots, finished worlds are re-seeded in the same launch.
+// Kernels (reference: AquaEnv.step, gym_aqua/envs/aqua.py:135-213; AquaEnv.reset, aqua.py:100-126)
+//   step_ns_kernel<AK, SMALL_TABLE>  one launch per batched step, next-step restart (auto_reset 2): the launch is
+//                          split by role -- a few re-seeding blocks at the head of the grid, stepping blocks of
+//                          256 worlds (one per lane) behind them -- with no synchronisation between the two.
+//                          The benchmarked kernel.
+//   step_kernel<VEC, AK>   one launch per batched step, no restart (auto_reset 0) or restart in the same launch
+//                          (auto_reset 1): 1024-world tiles, finished worlds re-seeded after one barrier.
 //   rollout_kernel<AK>     T steps in one launch with the world state held in registers.
-//   reset_kernel           masked reset (reference: AquaEnv.reset, aqua.py:100-126).
+//   reset_kernel           masked reset.   obs_norm_kernel  the DQN's normalised observation after a reset.
+//   ring_write_kernel<T>   one batch of rows into consecutive slots of a replay ring.
 //   tick_kernel            *tick_base += delta (tail node of a captured rollout graph).
-// HBM-bound integer/float streaming work: no MFMA anywhere (there is no contraction to feed it).
+// All of it is coalesced float/integer streaming work on struct-of-arrays rows; no MFMA anywhere (there is
+// no contraction to feed it).  Arithmetic shared by the kernels lives in aqua_device.hpp.
+//
+// Build-time switches (-D, all optional; tools/ab.py times variants against each other on one box):
+//   tuning      AQUA_NS_MAIN_WAVES (4) wavefronts per block of the next-step kernel; AQUA_NS_SCAN_ROWS (4) x 256 worlds
+//               scanned per re-seeding block; AQUA_NS_RESEED_GROUP (8) lanes per restarting world; AQUA_NS_TABLE_ROWS (8)
+//               largest table read from LDS by the re-seeding pass; AQUA_NS_RESEED_PRIO (3); AQUA_RESEED_ROWS_PER_STEP,
+//               AQUA_RESEED_UNROLL, AQUA_TILE, AQUA_RESET_GROUP, AQUA_STORE_HINT / AQUA_LOAD_HINT (cache scopes),
+//               AQUA_OBST_LDS, AQUA_INLINE_RESEED, AQUA_INLINE_EXACT, AQUA_BAND_TIGHT, AQUA_PHILOX_ROUNDS
+//   ablations   AQUA_NO_PAIR_PHILOX, AQUA_NO_ARG_BATCH
+//   experiments (results are NOT the product's): AQUA_NS_NOWORK (nobody restarts), AQUA_NS_NOMAIN (re-seeding
+//               blocks alone on a synthetic pending set), AQUA_EXP_NO_DEREF (table header and tick by value)
+//   diagnostics AQUA_STAMPS = 1 (phase stamps) | 2 (wavefront start/end only): tools/stamps*.py
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -278,9 +292,6 @@ __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u
 // boundaries, written to a buffer no product code reads.  Never defined in the shipped library.
 #ifndef AQUA_STAMPS
 #define AQUA_STAMPS 0
-#endif
-#ifndef AQUA_WORKER_PRIO
-#define AQUA_WORKER_PRIO 1
 #endif
 
 #if AQUA_STAMPS
