@@ -17,9 +17,15 @@ namespace aqua {
 
 constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band of the plain float32 margins, in world units
 #ifndef AQUA_BAND_TIGHT
-#define AQUA_BAND_TIGHT 4.0e-6f
+#define AQUA_BAND_TIGHT 2.0e-6f
 #endif
-constexpr float BAND_TIGHT = AQUA_BAND_TIGHT;    // ... of the error-compensated margins (second look, see fast_step)
+// ... of the error-compensated margins (second look, see fast_step).  Border and obstacles: what is left after the
+// compensation is the error of the displacement (<= 3.3e-7: hardware sin/cos 3.5e-7 x chord 0.5, the rounded
+// chord and angle, one fma, and the reference's own float64 cancellation on straight moves) plus, for obstacles,
+// the rounding of d^2 (covered by the 4 ulp(R^2) term of the per-obstacle band).  The goal distance goes through
+// two more roundings at magnitude 5 and a hardware sqrt (bound 1.2e-6, largest seen 1.3e-7): it keeps 4e-6.
+constexpr float BAND_TIGHT = AQUA_BAND_TIGHT;
+constexpr float BAND_TIGHT_GOAL = 4.0e-6f;
 constexpr int RESET_TRIES = 64;
 constexpr int MAX_OBST = 64;
 
@@ -29,7 +35,9 @@ constexpr int MAX_OBST = 64;
 struct ObstF {
     float cx, cy, hx, hy;       // box centre and half extents (aqua.py:381-384); circle: hx = hy = 0
     float r2;                   // R^2 with R = obstacle radius + 2.5 (circle) or 2.5 (rect)
-    float pad[3];
+    float w;                    // band2_tight(R_max) / band2_tight(R): scales this obstacle's compensated margin so
+                                // that ONE threshold (the header's) gives every obstacle the band of its own radius
+    float pad[2];
 };
 static_assert(sizeof(ObstF) == 32, "ObstF is two float4");
 
@@ -436,25 +444,28 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
         // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
         // by the rounding of x' = x + ddx itself (up to 3.8e-6).  Carry the rounding error of that sum
         // (xlo = ddx - (x' - x), exact: FastTwoSum) through the three margins; what is left is the error of
-        // ddx (~2.5e-7) and of d^2 (~4 ulp of R^2), so the band shrinks from 1e-4 to 4e-6 and the float64
+        // ddx (~3e-7) and of d^2 (~4 ulp of R^2), so the band shrinks from 1e-4 to 2e-6 (goal: 4e-6) and the float64
         // path -- whose length is added to the launch whenever ANY wavefront takes it -- is entered
         // ~25 times less often.
         const float xlo = ddx - (xn - e.x), ylo = ddy - (yn - e.y);
         const float mb2 = fminf(fminf((xn - 2.5f) + xlo, (yn - 2.5f) + ylo), fminf((97.5f - xn) - xlo, (97.5f - yn) - ylo));
         float mo2 = 3.0e38f;
+        // Each margin is scaled by its obstacle's w >= 1 (sign unchanged): |d^2 - R^2| < band2_tight(R_max) / w is the
+        // band of THAT obstacle's radius, 2.5 (R + BAND) BAND_TIGHT + 4 ulp(R^2) -- not R_max's, which for the
+        // R = 2.5 of every rectangle would be several times wider than its own in distance.
         for (int j = 0; j < k.Kc; ++j) {
             const float dx = (xn - k.obst[j].cx) + xlo, dy = (yn - k.obst[j].cy) + ylo;
-            mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
+            mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)) * k.obst[j].w);
         }
         for (int j = k.Kc; j < k.K; ++j) {
             const float dx = fmaxf(fabsf((xn - k.obst[j].cx) + xlo) - k.obst[j].hx, 0.0f);
             const float dy = fmaxf(fabsf((yn - k.obst[j].cy) + ylo) - k.obst[j].hy, 0.0f);
-            mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
+            mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)) * k.obst[j].w);
         }
         const float gx2 = (e.gx - xn) - xlo, gy2 = (e.gy - yn) - ylo;
         const float mg2 = __builtin_amdgcn_sqrtf(fmaf(gx2, gx2, gy2 * gy2)) - 5.0f;
         if (knife) { mc_f = mb2; mo_f = mo2; mg_f = mg2; }
-        knife = knife && ((fminf(fabsf(mb2), fabsf(mg2)) < BAND_TIGHT) || (fabsf(mo2) < k.band2_tight));
+        knife = knife && ((fabsf(mb2) < BAND_TIGHT) || (fabsf(mg2) < BAND_TIGHT_GOAL) || (fabsf(mo2) < k.band2_tight));
     }
     term = (fminf(mc_f, mo_f) < 0.0f) ? 1u : (tn > k.time_limit ? 2u : (mg_f <= 0.0f ? 3u : 0u));   // aqua.py:200-211
     reward = term == 0u ? shaped : (term == 3u ? 10.0f : -10.0f);

@@ -863,7 +863,11 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     const bool live = valid && !pending;
     AQUA_RTSTAMP(1);
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
+#ifdef AQUA_EXP_NO_EXACT                   // timing experiment only: what the float64 path costs the launch
+    const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live && false;
+#else
     const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
+#endif
     if (__builtin_expect(__any(knife) != 0, 0)) {
         if (knife) {
             const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
@@ -1279,8 +1283,12 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
     h->n_circles = n_circles;
     h->r_max = static_cast<float>(r_max);
     h->band2 = static_cast<float>(2.5 * (r_max + static_cast<double>(BAND)) * static_cast<double>(BAND));
-    h->band2_tight = static_cast<float>(2.5 * (r_max + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) +
-                                        4.0 * 1.1920929e-7 * r_max * r_max);
+    const auto tight = [](double R) {
+        return 2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) + 4.0 * 1.1920929e-7 * R * R;
+    };
+    h->band2_tight = static_cast<float>(tight(r_max));
+    for (int k = 0; k < K; ++k)                          // per-obstacle scale of the compensated margin (ObstF::w)
+        f[k].w = static_cast<float>(static_cast<double>(h->band2_tight) / tight(std::sqrt(static_cast<double>(f[k].r2))));
     return 0;
 }
 

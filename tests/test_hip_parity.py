@@ -136,6 +136,80 @@ def _compare_with_oracle(torch, oracle, env, state0, time0, action_np, reward, t
     return s64, t, o_term
 
 
+@pytest.mark.parametrize("obst,mode", [("bench8", 0), ("bench8", 2), ("default5", 0), ("difficult6", 2)])
+def test_decisions_at_the_thresholds_at_scale(torch, oracle, obst, mode):
+    """400 000 worlds per case whose POST-move position sits within +-3e-5 (log-uniform from 1e-9, both signs, and
+    exactly 0) of a border, of the goal radius or of an obstacle surface -- the recipe of the golden knife-edge rows
+    (tests/golden/make_golden.py), at the scale at which every band edge of the float32 path (plain 1e-4, compensated
+    4e-6 in distance, per obstacle radius) is crossed thousands of times.  Termination codes must equal the
+    float64 oracle's on every row; pose and reward within 1e-5."""
+    from aquaticgymenv_amd import presets
+    rows = {"bench8": presets.BENCH8, "default5": presets.DEFAULT5, "difficult6": presets.DIFFICULT6}[obst]
+    n = 400000
+    rng = np.random.RandomState(20261003 + mode)
+    disc = np.array([(0.2, 0.5), (0.5, 0.2), (0.5, 0.5)])
+    a = rng.randint(0, 3, n)
+    vl, vr = disc[a, 0], disc[a, 1]
+    theta = rng.uniform(-np.pi, np.pi, n).astype(np.float32).astype(np.float64)
+    d = vr - vl
+    d = np.copysign(np.maximum(np.abs(d), 1e-8), d)
+    w = d / 2.5
+    h = 0.5 * w
+    chord = 0.5 * (vl + vr) * np.sin(h) / h
+    dx, dy = -chord * np.sin(theta + h), chord * np.cos(theta + h)
+    wave = rng.uniform(-0.05, 0.05, (2, n)).astype(np.float32).astype(np.float64)
+    mag = 10.0 ** rng.uniform(-9, np.log10(3e-5), n)
+    delta = np.where(rng.randint(0, 50, n) == 0, 0.0, mag * rng.choice([-1.0, 1.0], n))
+    goal = rng.uniform(2.5, 97.5, (2, n))
+    p = rng.uniform(10, 90, (2, n))
+    what = rng.randint(0, 3, n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    # border
+    b = what == 0
+    axis = rng.randint(0, 2, n)
+    lowside = rng.randint(0, 2, n) == 1
+    val = np.where(lowside, 2.5 + delta, 97.5 - delta)
+    p[0] = np.where(b & (axis == 0), val, p[0])
+    p[1] = np.where(b & (axis == 1), val, p[1])
+    # goal radius
+    g = what == 1
+    goal[0] = np.where(g, p[0] + (5.0 + delta) * np.cos(ang), goal[0])
+    goal[1] = np.where(g, p[1] + (5.0 + delta) * np.sin(ang), goal[1])
+    # obstacle surfaces
+    o = what == 2
+    oi = rng.randint(0, rows.shape[0], n)
+    cx, cy, kind, pa, pb = (rows[oi, j] for j in range(5))
+    circ = kind == 0
+    px = cx + (pa + 2.5 + delta) * np.cos(ang)
+    py = cy + (pa + 2.5 + delta) * np.sin(ang)
+    hx, hy = pa / 2, pb / 2
+    side = rng.randint(0, 5, n)
+    u = rng.uniform(-1, 1, n)
+    a4 = rng.uniform(0, np.pi / 2, n)
+    rx = np.select([side == 0, side == 1, side == 2, side == 3],
+                   [cx + hx + 2.5 + delta, cx - hx - 2.5 - delta, cx + u * hx, cx + u * hx], cx + hx + (2.5 + delta) * np.cos(a4))
+    ry = np.select([side == 0, side == 1, side == 2, side == 3],
+                   [cy + u * hy, cy + u * hy, cy + hy + 2.5 + delta, cy - hy - 2.5 - delta], cy + hy + (2.5 + delta) * np.sin(a4))
+    p[0] = np.where(o, np.where(circ, px, rx), p[0])
+    p[1] = np.where(o, np.where(circ, py, ry), p[1])
+    state = np.stack([p[0] - dx - wave[0], p[1] - dy - wave[1], theta, goal[0], goal[1], wave[0], wave[1]]).astype(np.float32)
+    env = _make(torch, n, rows, seed=5150, auto_reset=mode)
+    env.reset()
+    env.set_state(state, rng.randint(0, 990, n).astype(np.int32), soa=True)
+    state0, time0 = _host_state(env)
+    tick = env._tick
+    act = a.astype(np.uint8)
+    obs, reward, term = env.step(torch.as_tensor(act).cuda())
+    torch.cuda.synchronize()
+    term_h = term.cpu().numpy()
+    if mode == 2:                                  # finished worlds keep their terminal pose and are marked
+        done = term_h != 0
+        tm = env.time[:n].cpu().numpy()
+        assert np.all(tm[done] == -1 - (tick & 1)) and np.all(tm[~done] == time0[~done] + 1)
+    _compare_with_oracle(torch, oracle, env, state0, time0, act, reward.cpu().numpy(), term_h, tick)
+    assert 0.05 < float((term_h == 1).mean()) < 0.6 and float((term_h == 3).mean()) > 0.05      # both sides of each threshold
+
+
 @pytest.mark.parametrize("n,continuous,obst", [(4096, False, "none"), (262144, False, "bench8"), (262144, True, "bench8"),
                                                (1000, True, "default5"), (65, False, "difficult6")])
 def test_step_matches_oracle_philox(torch, oracle, vec, n, continuous, obst):
