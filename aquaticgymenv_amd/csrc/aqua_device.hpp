@@ -439,6 +439,9 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float shaped = dsum > 0.0f ? 0.7f * (num * __builtin_amdgcn_rcpf(dsum)) : 0.0f;
 
     bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
+#ifdef AQUA_EXP_NO_SECOND                  // timing experiment only: what the second look (and everything behind it) costs
+    knife = false;
+#endif
     float mc_f = mc, mo_f = mo, mg_f = mg;
     if (__builtin_expect(__any(knife) != 0, 0)) {
         // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
@@ -646,6 +649,9 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
         const float sbx = __shfl(cbx, bsrc), sby = __shfl(cby, bsrc);
         if (goal_found && !boat_done && !serial && bm) { bx = sbx; by = sby; bt = heading; boat_done = true; }
         if (!__any((!goal_found || !boat_done) && !serial)) break;
+#ifdef AQUA_EXP_ONE_ROUND                  // timing experiment only: what the later rounds of the re-seeding cost
+        break;
+#endif
     }
     // goal attempts exhausted: the goal stays at its fixed default (aqua.py:107) and the boat is still scanned
     if (active && random_boat && !boat_done && !goal_found) serial = true;
