@@ -18,7 +18,7 @@ SYMBOLS = (
     "aqua_reset_f32", "aqua_rollout_f32", "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin",
     "aqua_graph_end", "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width",
     "aqua_discrete_constants", "aqua_set_vector_width", "aqua_obs_norm_f32",
-    "aqua_ring_write_f32", "aqua_ring_write_u8",
+    "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
 )
 
 
@@ -59,6 +59,10 @@ def _load():
     lib.aqua_obs_norm_f32.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.aqua_ring_write_f32.argtypes = [vp, i64, i64, i64, vp, i64, ci, i64, vp]
     lib.aqua_ring_write_u8.argtypes = [vp, i64, i64, i64, vp, i64, ci, i64, vp]
+    lib.aqua_pack_tables.argtypes = [vp, ci, i64, i64, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.aqua_step_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, vp, ci, i64, vp, i64,
+                                         u64, u64, vp, vp, vp, vp, vp, vp]
+    lib.aqua_reset_tables_f32.argtypes = [pp, vp, ci, i64, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_graph_begin.argtypes = [vp]
     lib.aqua_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
     lib.aqua_graph_launch.argtypes = [vp, vp]
@@ -70,7 +74,8 @@ def _load():
     for name in ("aqua_pack_obstacles", "aqua_step_f32", "aqua_reset_f32", "aqua_rollout_f32",
                  "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin", "aqua_graph_end",
                  "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width", "aqua_set_vector_width",
-                 "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8"):
+                 "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
+                 "aqua_step_tables_f32", "aqua_reset_tables_f32"):
         getattr(lib, name).restype = ci
     if lib.aqua_version() != ABI_VERSION:
         raise ImportError("libaqua_hip.so ABI %d != binding %d: rebuild" % (lib.aqua_version(), ABI_VERSION))

@@ -83,8 +83,18 @@ class BatchedAqua(object):
         self.auto_reset = modes[auto_reset]
         self.has_waves = int(waves)                   # aqua.py:15
         self.seed = int(seed) if seed is not None else int(np.random.SeedSequence().entropy & ((1 << 64) - 1))
-        self.obstacle_rows = presets.rows_from(obstacles)
-        self.K = int(self.obstacle_rows.shape[0])
+        # obstacles: False/True/list/[K][5] -> ONE list for the whole batch (presets.rows_from);
+        #            float [N][K][5] -> one list PER WORLD (rows with kind < 0 are absent), include/aqua_hip.h
+        self.per_world = isinstance(obstacles, np.ndarray) and obstacles.ndim == 3
+        if self.per_world:
+            if obstacles.shape[0] != num_envs or obstacles.shape[2] != 5 or obstacles.shape[1] < 1:
+                raise ValueError("per-world obstacle tables must have shape [num_envs][K >= 1][5]")
+            self.obstacle_tables = np.ascontiguousarray(obstacles, dtype=np.float64)
+            self.obstacle_rows = presets.rows_from(False)
+            self.K = int(obstacles.shape[1])
+        else:
+            self.obstacle_rows = presets.rows_from(obstacles)
+            self.K = int(self.obstacle_rows.shape[0])
         self.params = _capi.AquaParams(waves=self.has_waves, continuous=int(self.continuous),
                                        random_boat=int(bool(random_boat)), random_goal=int(bool(random_goal)),
                                        time_limit=TIME_LIMIT)
@@ -96,7 +106,18 @@ class BatchedAqua(object):
             self.reward = torch.zeros(self.ld, dtype=torch.float32, device=dev)
             self.term = torch.zeros(self.ld, dtype=torch.uint8, device=dev)
             self.done_bits = torch.zeros(self.ld // 64, dtype=torch.int64, device=dev)
-            blob = _capi.pack_obstacles(self.obstacle_rows)
+            self._tab32 = self._tab64 = None
+            self._r_max = 0.0
+            if self.per_world:
+                if self.auto_reset != 0:
+                    raise ValueError("per-world obstacle tables: auto_reset must be False (reset(mask=term != 0) restarts worlds)")
+                t32 = np.zeros((self.K, 6, self.ld), dtype=np.float32)
+                t64 = np.zeros((self.K, 5, self.ld), dtype=np.float64)
+                r_max = ctypes.c_float(0.0)
+                _capi.check(_capi.lib.aqua_pack_tables(self.obstacle_tables.ctypes.data, self.K, n, self.ld, t32.ctypes.data,
+                                                       t64.ctypes.data, ctypes.byref(r_max)), "aqua_pack_tables")
+                self._tab32, self._tab64, self._r_max = torch.from_numpy(t32).to(dev), torch.from_numpy(t64).to(dev), r_max.value
+            blob = _capi.pack_obstacles(self.obstacle_rows) if not self.per_world else b""
             if blob:
                 host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
                 self._blob = host.to(dev)
@@ -201,10 +222,17 @@ class BatchedAqua(object):
             mask = mask.contiguous()
             mptr = mask.data_ptr()
         with torch.cuda.device(self.device):
-            _capi.check(_capi.lib.aqua_reset_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
-                                                 self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
-                                                 mptr, self.seed, self.RESET_TICK_BASE + self._resets, None,
-                                                 self._stream()), "aqua_reset_f32")
+            if self.per_world:
+                _capi.check(_capi.lib.aqua_reset_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self.K, self.ld,
+                                                            self.num_envs, self.env_offset, self.state.data_ptr(), self.ld,
+                                                            self.time.data_ptr(), mptr, self.seed,
+                                                            self.RESET_TICK_BASE + self._resets, None, self._stream()),
+                            "aqua_reset_tables_f32")
+            else:
+                _capi.check(_capi.lib.aqua_reset_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                                     self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
+                                                     mptr, self.seed, self.RESET_TICK_BASE + self._resets, None,
+                                                     self._stream()), "aqua_reset_f32")
             if self._norm_ptr() is not None:          # the step kernels' epilogue, for the worlds just placed
                 _capi.check(_capi.lib.aqua_obs_norm_f32(self.state.data_ptr(), self.ld, self.num_envs, mptr,
                                                         self._norm_ptr(), self._stream()), "aqua_obs_norm_f32")
@@ -237,16 +265,27 @@ class BatchedAqua(object):
                 raise ValueError("noise must be float32 [2][>=N] with unit inner stride")
             nptr, nld = noise.data_ptr(), noise.stride(0)
         with torch.cuda.device(self.device):
-            _capi.check(_capi.lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
-                                                self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald,
-                                                nptr, nld, self.seed, self._tick, None, self.reward.data_ptr(),
-                                                self.term.data_ptr(), self.done_bits.data_ptr(), self._norm_ptr(),
-                                                int(self.auto_reset), self._stream()), "aqua_step_f32")
+            if self.per_world:
+                _capi.check(_capi.lib.aqua_step_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(),
+                                                           self._tab64.data_ptr(), self.K, self.ld, self._r_max, n,
+                                                           self.env_offset, self.state.data_ptr(), self.ld,
+                                                           self.time.data_ptr(), aptr, kind, ald, nptr, nld, self.seed,
+                                                           self._tick, None, self.reward.data_ptr(), self.term.data_ptr(),
+                                                           self.done_bits.data_ptr(), self._norm_ptr(), self._stream()),
+                            "aqua_step_tables_f32")
+            else:
+                _capi.check(_capi.lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
+                                                    self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald,
+                                                    nptr, nld, self.seed, self._tick, None, self.reward.data_ptr(),
+                                                    self.term.data_ptr(), self.done_bits.data_ptr(), self._norm_ptr(),
+                                                    int(self.auto_reset), self._stream()), "aqua_step_f32")
         self._tick += 1
         del keep
         return self.obs, self.reward[:n], self.term[:n]
 
     def _rollout_args(self, steps, actions, soa_ld):
+        if self.per_world:
+            raise NotImplementedError("per-world obstacle tables are stepped one launch at a time (step())")
         torch = self.torch
         n = self.num_envs
         if actions is None or isinstance(actions, str):
@@ -351,6 +390,54 @@ class BatchedAqua(object):
         g = RolloutGraph(self, handle, steps, reward, term)
         g._actions = actions          # keep the action buffer alive as long as the graph
         g.done_history = done if dstride else None
+        return g
+
+    def capture_steps_per_world(self, steps, actions):
+        """Per-world obstacle tables: capture `steps` x (one step launch + one masked reset of the worlds that just
+        finished, mask = the step's termination codes) into a HIP graph.  actions: uint8 [steps][ld] (discrete).
+        Ticks come from the device-resident base like capture_rollout()'s, so replays draw fresh noise."""
+        if not self.per_world or self.continuous:
+            raise NotImplementedError("capture_steps_per_world: discrete worlds with per-world obstacle tables")
+        torch = self.torch
+        if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[0] < steps or actions.shape[1] < self.num_envs \
+                or actions.stride(1) != 1:
+            raise ValueError("actions must be uint8 [steps][>=N]")
+        lib = _capi.lib
+        self._sync_device_tick()
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device), torch.cuda.stream(cap):
+            s = self._stream()
+            _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
+            rc = 0
+            try:
+                tb = self._tick_dev.data_ptr()
+                for i in range(steps):
+                    rc = lib.aqua_step_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),
+                                                  self.K, self.ld, self._r_max, self.num_envs, self.env_offset,
+                                                  self.state.data_ptr(), self.ld, self.time.data_ptr(),
+                                                  actions[i].data_ptr(), _capi.ACT_U8, 0, None, 0, self.seed, i, tb,
+                                                  self.reward.data_ptr(), self.term.data_ptr(), self.done_bits.data_ptr(),
+                                                  self._norm_ptr(), s)
+                    if rc:
+                        break
+                    # restart what just finished: its draws use the restart range of this tick (tick base + i)
+                    rc = lib.aqua_reset_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self.K, self.ld,
+                                                   self.num_envs, self.env_offset, self.state.data_ptr(), self.ld,
+                                                   self.time.data_ptr(), self.term.data_ptr(), self.seed,
+                                                   self.RESET_TICK_BASE // 2 + i, tb, s)
+                    if rc:
+                        break
+                if rc == 0:
+                    rc = lib.aqua_tick_advance(tb, steps, s)
+            finally:
+                rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
+            _capi.check(rc, "capture per-world steps")
+            _capi.check(rc_end, "aqua_graph_end")
+        torch.cuda.current_stream(self.device).wait_stream(cap)
+        g = RolloutGraph(self, handle, steps, self.reward, self.term)
+        g._actions = actions
         return g
 
     # ------------------------------------------------------------------ helpers

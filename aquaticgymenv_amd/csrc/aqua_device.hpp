@@ -316,6 +316,26 @@ __device__ __forceinline__ ExactMotion exact_motion_continuous(double vl, double
     return m;
 }
 
+// Per-world obstacle tables (domain randomisation: every world of the batch has its own list, as every env object
+// of the reference has, aqua.py:56-68).  Struct of arrays over the worlds so that a wavefront's reads coalesce:
+//   t32  float32 [K][6][ld]   row j of world i at t32[(6 j + c) ld + i],  c = cx, cy, hx, hy, r2, w  (ObstF's fields;
+//                             an absent row has r2 = -3e38 and never wins a minimum)
+//   t64  float64 [K][5][ld]   the reference's own row (cx, cy, kind, a, b; kind < 0: absent), for the float64 path
+struct WorldTable {
+    const float* t32;
+    const double* t64;
+    int64_t ld;
+    int64_t i;                  // this lane's world
+};
+__device__ __forceinline__ ObstF world_row(const WorldTable& t, int j)
+{
+    ObstF r;
+    const float* p = t.t32 + (6 * j) * t.ld + t.i;
+    r.cx = p[0]; r.cy = p[t.ld]; r.hx = p[2 * t.ld]; r.hy = p[3 * t.ld]; r.r2 = p[4 * t.ld]; r.w = p[5 * t.ld];
+    r.pad[0] = r.pad[1] = 0.0f;
+    return r;
+}
+
 #ifndef AQUA_INLINE_EXACT
 #define AQUA_INLINE_EXACT 0
 #endif
@@ -324,16 +344,19 @@ __device__ __forceinline__ ExactMotion exact_motion_continuous(double vl, double
 #else
 #define AQUA_EXACT_ATTR __noinline__
 #endif
-__device__ AQUA_EXACT_ATTR ExactOut exact_step(float fx, float fy, float fth, float fgx, float fgy, float fwx,
-                                            float fwy, int t_new, ExactMotion mo, int K,
-                                            const double* __restrict__ obst64, ObstPtr obst32, float band2,
-                                            int time_limit)
+template <bool PER_WORLD>
+__device__ AQUA_EXACT_ATTR ExactOut exact_step_impl(float fx, float fy, float fth, float fgx, float fgy, float fwx,
+                                                 float fwy, int t_new, ExactMotion mo, int K,
+                                                 const double* __restrict__ obst64, ObstPtr obst32, float band2,
+                                                 int time_limit, WorldTable wt)
 {
 #pragma clang fp contract(off)
     constexpr double PI_D = 3.141592653589793;
     K = uni(K); band2 = uni(band2); time_limit = uni(time_limit);
-    obst32 = uni_ptr(obst32);
-    obst64 = (const double*)uni((uint64_t)(uintptr_t)obst64);
+    if constexpr (!PER_WORLD) {
+        obst32 = uni_ptr(obst32);
+        obst64 = (const double*)uni((uint64_t)(uintptr_t)obst64);
+    }
     const double px = fx, py = fy, th = fth, gx = fgx, gy = fgy;
     const double r = mo.r, w = mo.w, c = mo.cw, s = mo.sw;
     const double angle = PI_D / 2 + th;
@@ -354,11 +377,21 @@ __device__ AQUA_EXACT_ATTR ExactOut exact_step(float fx, float fy, float fth, fl
     bool hit = (nx - 2.5 < 0.0) || (ny - 2.5 < 0.0) || (nx + 2.5 > 100.0) || (ny + 2.5 > 100.0);
     const float xs = static_cast<float>(nx), ys = static_cast<float>(ny);
     for (int k = 0; k < K; ++k) {
-        const float bx = fmaxf(fabsf(xs - obst32[k].cx) - obst32[k].hx, 0.0f);
-        const float by = fmaxf(fabsf(ys - obst32[k].cy) - obst32[k].hy, 0.0f);
-        const float m32 = fmaf(bx, bx, fmaf(by, by, -obst32[k].r2));
+        ObstF row;
+        if constexpr (PER_WORLD) row = world_row(wt, k);
+        else { row.cx = obst32[k].cx; row.cy = obst32[k].cy; row.hx = obst32[k].hx; row.hy = obst32[k].hy; row.r2 = obst32[k].r2; }
+        const float bx = fmaxf(fabsf(xs - row.cx) - row.hx, 0.0f);
+        const float by = fmaxf(fabsf(ys - row.cy) - row.hy, 0.0f);
+        const float m32 = fmaf(bx, bx, fmaf(by, by, -row.r2));
         if (fabsf(m32) >= band2) { hit = hit || (m32 < 0.0f); continue; }
-        const double* o = obst64 + 5 * k;
+        double o[5];
+        if constexpr (PER_WORLD) {
+#pragma unroll
+            for (int c5 = 0; c5 < 5; ++c5) o[c5] = wt.t64[(5 * k + c5) * wt.ld + wt.i];
+        } else {
+#pragma unroll
+            for (int c5 = 0; c5 < 5; ++c5) o[c5] = obst64[5 * k + c5];
+        }
         double dist;
         if (o[2] == 0.0) {
             const double dx = o[0] - nx, dy = o[1] - ny;
@@ -389,6 +422,19 @@ __device__ AQUA_EXACT_ATTR ExactOut exact_step(float fx, float fy, float fth, fl
     return out;
 }
 
+__device__ __forceinline__ ExactOut exact_step(float fx, float fy, float fth, float fgx, float fgy, float fwx, float fwy,
+                                               int t_new, ExactMotion mo, int K, const double* __restrict__ obst64,
+                                               ObstPtr obst32, float band2, int time_limit)
+{
+    return exact_step_impl<false>(fx, fy, fth, fgx, fgy, fwx, fwy, t_new, mo, K, obst64, obst32, band2, time_limit, WorldTable{});
+}
+__device__ __forceinline__ ExactOut exact_step_world(float fx, float fy, float fth, float fgx, float fgy, float fwx,
+                                                     float fwy, int t_new, ExactMotion mo, int K, float band2,
+                                                     int time_limit, const WorldTable& wt)
+{
+    return exact_step_impl<true>(fx, fy, fth, fgx, fgy, fwx, fwy, t_new, mo, K, nullptr, nullptr, band2, time_limit, wt);
+}
+
 // ------------------------------------------------------------------------------------ fast path
 // Advances one world in float32.  Returns true when a margin falls inside the knife-edge band
 // (the caller then overrides pose/reward/term with exact_step()).
@@ -400,8 +446,11 @@ __device__ AQUA_EXACT_ATTR ExactOut exact_step(float fx, float fy, float fth, fl
 // reference's OR-of-tests; |d^2 - R^2| < band2 = 2.5 R_max BAND covers |d - R| < BAND for every R <= R_max,
 // and the strict/non-strict difference of the reference's comparisons only matters at margin == 0,
 // which is inside the band by construction.
+// PER_WORLD: the obstacle rows come from this lane's own table (`wt`, generic box formula for every row) instead of
+// the batch's shared one.
+template <bool PER_WORLD = false>
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
-                                          const StepConst& k, float& reward, uint32_t& term)
+                                          const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr)
 {
     float s, c;
     sincos_bounded(e.th + h, s, c);
@@ -416,6 +465,15 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
 
     const float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
     float mo = 3.0e38f;                                    // min over obstacles of d^2 - R^2
+    if constexpr (PER_WORLD) {
+#pragma unroll 2
+        for (int j = 0; j < k.K; ++j) {                    // a circle is a box with zero half extents: same bits
+            const ObstF r = world_row(*wt, j);
+            const float dx = fmaxf(fabsf(xn - r.cx) - r.hx, 0.0f);
+            const float dy = fmaxf(fabsf(yn - r.cy) - r.hy, 0.0f);
+            mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -r.r2)));
+        }
+    } else {
 #pragma unroll 2
     for (int j = 0; j < k.Kc; ++j) {                       // circles: distance to the centre
         const float dx = xn - k.obst[j].cx, dy = yn - k.obst[j].cy;
@@ -426,6 +484,7 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
         const float dx = fmaxf(fabsf(xn - k.obst[j].cx) - k.obst[j].hx, 0.0f);
         const float dy = fmaxf(fabsf(yn - k.obst[j].cy) - k.obst[j].hy, 0.0f);
         mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)));
+    }
     }
     // goal distance and shaped reward (aqua.py:89-90, 392-402, 421-422).  prev - cur is formed
     // from the displacement, (|a|^2 - |b|^2) / (|a| + |b|), not as a difference of two norms.
@@ -456,6 +515,14 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
         // Each margin is scaled by its obstacle's w >= 1 (sign unchanged): |d^2 - R^2| < band2_tight(R_max) / w is the
         // band of THAT obstacle's radius, 2.5 (R + BAND) BAND_TIGHT + 4 ulp(R^2) -- not R_max's, which for the
         // R = 2.5 of every rectangle would be several times wider than its own in distance.
+        if constexpr (PER_WORLD) {
+            for (int j = 0; j < k.K; ++j) {
+                const ObstF r = world_row(*wt, j);
+                const float dx = fmaxf(fabsf((xn - r.cx) + xlo) - r.hx, 0.0f);
+                const float dy = fmaxf(fabsf((yn - r.cy) + ylo) - r.hy, 0.0f);
+                mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -r.r2)) * r.w);
+            }
+        } else {
         for (int j = 0; j < k.Kc; ++j) {
             const float dx = (xn - k.obst[j].cx) + xlo, dy = (yn - k.obst[j].cy) + ylo;
             mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)) * k.obst[j].w);
@@ -464,6 +531,7 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
             const float dx = fmaxf(fabsf((xn - k.obst[j].cx) + xlo) - k.obst[j].hx, 0.0f);
             const float dy = fmaxf(fabsf((yn - k.obst[j].cy) + ylo) - k.obst[j].hy, 0.0f);
             mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -k.obst[j].r2)) * k.obst[j].w);
+        }
         }
         const float gx2 = (e.gx - xn) - xlo, gy2 = (e.gy - yn) - ylo;
         const float mg2 = __builtin_amdgcn_sqrtf(fmaf(gx2, gx2, gy2 * gy2)) - 5.0f;
@@ -528,6 +596,82 @@ __device__ __noinline__ EnvState reset_env(uint64_t seed, uint64_t env, uint64_t
             const float g2 = fmaf(ex, ex, ey2);
             if (g2 <= 25.0f) continue;
             if (reset_hit(K, t, cx, cy)) continue;
+            bx = cx; by = cy; bt = heading;
+            break;
+        }
+    }
+    e.x = bx; e.y = by; e.th = bt; e.gx = gx; e.gy = gy;
+    e.t = 0;                                               // aqua.py:125
+    return e;
+}
+
+// The same specification against this lane's own table (per-world tables): the serial loop, one world per lane.
+// Tables of up to WORLD_ROWS_IN_REGS rows are read ONCE into registers (all loads in flight together, one memory
+// round trip) and every hit test after that is arithmetic only; longer tables are re-read per test.
+constexpr int WORLD_ROWS_IN_REGS = 8;
+struct WorldRows {
+    ObstF r[WORLD_ROWS_IN_REGS];
+    bool cached;
+};
+__device__ __forceinline__ bool reset_hit_world(int K, const WorldTable& t, const WorldRows& rows, float px, float py)
+{
+#pragma clang fp contract(off)
+    bool hit = false;
+    auto test = [&](const ObstF& r) {
+        const float ax = fabsf(px - r.cx), ay = fabsf(py - r.cy);
+        const float dx = fmaxf(ax - r.hx, 0.0f), dy = fmaxf(ay - r.hy, 0.0f);
+        const float dy2 = dy * dy;
+        const float d2 = fmaf(dx, dx, dy2);
+        hit |= d2 <= r.r2;
+    };
+    if (rows.cached) {
+#pragma unroll
+        for (int j = 0; j < WORLD_ROWS_IN_REGS; ++j) test(rows.r[j]);       // absent rows: r2 = -3e38, never hit
+    } else {
+        for (int j = 0; j < K; ++j) test(world_row(t, j));
+    }
+    return hit;
+}
+
+__device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env, uint64_t tick, int waves, int random_boat,
+                                                    int random_goal, int K, const WorldTable& t)
+{
+#pragma clang fp contract(off)
+    WorldRows rows;
+    rows.cached = K <= WORLD_ROWS_IN_REGS;                 // uniform
+#pragma unroll
+    for (int j = 0; j < WORLD_ROWS_IN_REGS; ++j) {
+        if (rows.cached && j < K) rows.r[j] = world_row(t, j);
+        else { rows.r[j].cx = rows.r[j].cy = rows.r[j].hx = rows.r[j].hy = 0.0f; rows.r[j].r2 = -3.0e38f; rows.r[j].w = 1.0f; }
+    }
+    EnvState e;
+    constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    uint32_t r[4];
+    float gx = 25.0f, gy = 80.0f;                          // aqua.py:107
+    if (random_goal) {
+        for (uint32_t a = 0; a < RESET_TRIES; ++a) {       // aqua.py:103-105
+            draw(seed, env, tick, STREAM_PLACE, a, r);
+            const float cx = fmaf(95.0f, u_01(r[0]), 2.5f);
+            const float cy = fmaf(95.0f, u_01(r[1]), 2.5f);
+            if (!reset_hit_world(K, t, rows, cx, cy)) { gx = cx; gy = cy; break; }
+        }
+    }
+    draw(seed, env, tick, STREAM_POSE, 0, r);              // heading (aqua.py:111) and wave (aqua.py:124)
+    const float W = 0.05f * static_cast<float>(waves);
+    const float heading = fmaf(TWO_PI_F, u_01(r[0]), -PI_F);
+    e.wx = W * u_pm1(r[1]);
+    e.wy = W * u_pm1(r[2]);
+    float bx = 85.0f, by = 45.0f, bt = 0.0f;               // aqua.py:117
+    if (random_boat) {
+        for (uint32_t a = 0; a < RESET_TRIES; ++a) {       // aqua.py:111-115
+            draw(seed, env, tick, STREAM_PLACE, a, r);
+            const float cx = fmaf(95.0f, u_01(r[2]), 2.5f);
+            const float cy = fmaf(95.0f, u_01(r[3]), 2.5f);
+            const float ex = gx - cx, ey = gy - cy;
+            const float ey2 = ey * ey;
+            const float g2 = fmaf(ex, ex, ey2);
+            if (g2 <= 25.0f) continue;
+            if (reset_hit_world(K, t, rows, cx, cy)) continue;
             bx = cx; by = cy; bt = heading;
             break;
         }

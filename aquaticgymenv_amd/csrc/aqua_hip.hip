@@ -1010,6 +1010,109 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
     }
 }
 
+// ------------------------------------------------------------------ per-world obstacle tables
+// One launch per batched step, no restart (the caller resets with reset_tables_kernel): one world per lane, every
+// lane reads the rows of its own table (WorldTable, struct of arrays over the worlds: coalesced), generic box
+// formula for every row.  The arithmetic, the bands and the float64 path are the shared-table kernels'.
+template <int AK>
+__global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
+                                                                  const double* __restrict__ t64, int64_t tld,
+                                                                  float band2, float band2_tight)
+{
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL;
+    const int64_t ld = a.ld, rem = a.N - tile;
+    const int lane = threadIdx.x & 63;
+    float* const row0 = a.state + tile;
+    int32_t* const trow = a.time + tile;
+    const uint32_t last = static_cast<uint32_t>(rem < BLOCK_SMALL ? rem - 1 : BLOCK_SMALL - 1);
+    const uint32_t off = threadIdx.x;
+    const bool valid = static_cast<int64_t>(off) < rem;
+    const uint32_t o = off < last ? off : last;
+    const uint32_t o4 = o * 4u;
+    float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
+    int64_t araw[1] = {2};
+    int aidx[1] = {2};
+    const int32_t t0 = ld_at(trow, o4);
+    x[0] = ld_at(row0 + 0 * ld, o4); y[0] = ld_at(row0 + 1 * ld, o4); th[0] = ld_at(row0 + 2 * ld, o4);
+    gx[0] = ld_at(row0 + 3 * ld, o4); gy[0] = ld_at(row0 + 4 * ld, o4);
+    wx[0] = ld_at(row0 + 5 * ld, o4); wy[0] = ld_at(row0 + 6 * ld, o4);
+    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action) + tile, o);
+    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action) + tile, o4);
+    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action) + tile, o * 8u);
+    else if constexpr (AK == AQUA_ACT_F32X2) {
+        avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
+        avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
+    }
+    StepConst k;
+    k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K; k.Kc = 0;
+    k.band2 = band2; k.band2_tight = band2_tight; k.obst = nullptr; k.obst64 = nullptr;
+    k.touch[0] = k.touch[1] = k.touch[2] = k.touch[3] = 0;
+    const uint64_t tick = launch_tick(a);
+    const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
+    if (a.noise == nullptr) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
+        u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
+    } else {
+        u0[0] = ld_at(a.noise + tile, o4);
+        u1[0] = ld_at(a.noise + a.noise_ld + tile, o4);
+    }
+    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
+        if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
+        else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
+    }
+    fold_actions<1, AK>(araw, aidx);
+    if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
+    const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
+    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
+    const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
+    const WorldTable wt{t32, t64, tld, tile + o};
+    float rew;
+    uint32_t code;
+    const bool knife = fast_step<true>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt) && valid;
+    if (__builtin_expect(__any(knife) != 0, 0)) {
+        if (knife) {
+            const ExactOut o2 = exact_step_world(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.band2,
+                                                 k.time_limit, wt);
+            e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
+        }
+    }
+    const bool done = valid && code != 0u;
+    if (valid) {
+        st_at(a.reward + tile, o4, rew);
+        st_at(a.term + tile, o, static_cast<uint8_t>(code));
+        st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
+        st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
+        st_at(trow, o4, e.t);
+        write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
+    }
+    if (a.done_bits != nullptr) {
+        const uint64_t b = __ballot(done);
+        const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArgs a, const uint8_t* __restrict__ mask,
+                                                                   const float* __restrict__ t32, int64_t tld)
+{
+    const uint64_t tick = launch_tick(a);
+    const int64_t N = a.N, ld = a.ld;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
+         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+        if (mask != nullptr && mask[i] == 0) continue;
+        const WorldTable wt{t32, nullptr, tld, i};
+        const EnvState e = reset_env_world(a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat,
+                                           a.random_goal, a.K, wt);
+        a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
+        a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
+        a.state[5 * ld + i] = e.wx; a.state[6 * ld + i] = e.wy;
+        a.time[i] = e.t;
+    }
+}
+
 // ------------------------------------------------------------------ masked reset
 __global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, const uint8_t* __restrict__ mask)
 {
@@ -1500,6 +1603,116 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_rollout_fused_f32 launch");
+}
+
+int aqua_pack_tables(const double* rows, int K, int64_t N, int64_t tld, float* tab32_host, double* tab64_host, float* r_max_out)
+{
+    if (K < 1 || K > AQUA_MAX_OBSTACLES) return fail(AQUA_E_INVALID, "K=%d outside [1, %d]", K, AQUA_MAX_OBSTACLES);
+    if (N < 0 || tld < N) return fail(AQUA_E_INVALID, "bad sizes: N=%lld tld=%lld", (long long)N, (long long)tld);
+    if (rows == nullptr || tab32_host == nullptr || tab64_host == nullptr || r_max_out == nullptr)
+        return fail(AQUA_E_INVALID, "rows/tab32/tab64/r_max is NULL");
+    const auto tight = [](double R) {
+        return 2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) + 4.0 * 1.1920929e-7 * R * R;
+    };
+    double r_max = 2.5;                                  // a rectangle's (and the smallest possible) collision radius
+    for (int64_t i = 0; i < N; ++i)
+        for (int k = 0; k < K; ++k) {
+            const double* o = rows + (i * K + k) * 5;
+            if (o[2] < 0.0) continue;
+            if (!(o[2] == 0.0 || o[2] == 1.0)) return fail(AQUA_E_INVALID, "world %lld obstacle %d: kind must be 0, 1 or < 0", (long long)i, k);
+            if (o[3] < 0.0 || (o[2] == 1.0 && o[4] < 0.0)) return fail(AQUA_E_INVALID, "world %lld obstacle %d: negative size", (long long)i, k);
+            if (o[2] == 0.0 && 2.5 + o[3] > r_max) r_max = 2.5 + o[3];
+        }
+    const float b_max = static_cast<float>(tight(r_max));
+    for (int64_t i = 0; i < N; ++i)
+        for (int k = 0; k < K; ++k) {
+            const double* o = rows + (i * K + k) * 5;
+            float* f = tab32_host + (6 * k) * tld + i;
+            double* d = tab64_host + (5 * k) * tld + i;
+            for (int c = 0; c < 5; ++c) d[c * tld] = o[c];
+            if (o[2] < 0.0) {                            // absent: never hit, never in band
+                f[0] = f[tld] = f[2 * tld] = f[3 * tld] = 0.0f; f[4 * tld] = -3.0e38f; f[5 * tld] = 1.0f;
+                continue;
+            }
+            double hx = 0, hy = 0, R = 2.5;
+            if (o[2] == 0.0) R += o[3]; else { hx = o[3] / 2; hy = o[4] / 2; }
+            f[0] = static_cast<float>(o[0]); f[tld] = static_cast<float>(o[1]);
+            f[2 * tld] = static_cast<float>(hx); f[3 * tld] = static_cast<float>(hy);
+            const float r2 = static_cast<float>(R * R);
+            f[4 * tld] = r2;
+            f[5 * tld] = static_cast<float>(static_cast<double>(b_max) / tight(std::sqrt(static_cast<double>(r2))));
+        }
+    *r_max_out = static_cast<float>(r_max);
+    return 0;
+}
+
+namespace {
+int fill_table_args(StepArgs& a, const AquaParams* p, const float* tab32, int K, int64_t tld, int64_t N, int64_t env_offset,
+                    float* state, int64_t ld, int32_t* time, uint64_t seed, uint64_t tick, const uint64_t* tick_base)
+{
+    if (K < 1) return fail(AQUA_E_INVALID, "K=%d: per-world tables need at least one row", K);
+    if (tab32 == nullptr) return fail(AQUA_E_INVALID, "tab32 is NULL");
+    if (tld < N) return fail(AQUA_E_INVALID, "tld=%lld < N=%lld", (long long)tld, (long long)N);
+    if (!aligned(tab32, 4)) return fail(AQUA_E_ALIGN, "tab32 must be 4-byte aligned");
+    const int rc = fill_args(a, p, nullptr, 0, N, env_offset, state, ld, time, seed, tick, tick_base);
+    if (rc) return rc;
+    a.K = K;
+    return 0;
+}
+}  // namespace
+
+int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                         float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time,
+                         const void* action, int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld,
+                         uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                         uint64_t* done_bits, float* obs_norm, void* stream)
+{
+    StepArgs a;
+    int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
+    if (rc) return rc;
+    if (tab64_dev == nullptr || !aligned(tab64_dev, 8)) return fail(AQUA_E_INVALID, "tab64 is NULL or not 8-byte aligned");
+    if (!(r_max >= 2.5f)) return fail(AQUA_E_INVALID, "r_max=%g: use the value aqua_pack_tables returned", (double)r_max);
+    rc = check_step_buffers(N, action, action_kind, action_ld, noise, noise_ld, reward, term);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
+    a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = AQUA_RESET_NONE;
+    const double R = static_cast<double>(r_max);
+    const float band2 = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND));
+    const float band2_tight = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) +
+                                                 4.0 * 1.1920929e-7 * R * R);
+    const int64_t blocks = (N + BLOCK_SMALL - 1) / BLOCK_SMALL;
+    if (blocks > MAX_GRID) return fail(AQUA_E_INVALID, "N too large for one launch");
+    const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define AQUA_TAB_LAUNCH(AK) case AK: hipLaunchKernelGGL((step_tables_kernel<AK>), grid, block, 0, s, a, tab32_dev, tab64_dev, tld, band2, band2_tight); break;
+    switch (action_kind) {
+        AQUA_TAB_LAUNCH(AQUA_ACT_U8)
+        AQUA_TAB_LAUNCH(AQUA_ACT_I32)
+        AQUA_TAB_LAUNCH(AQUA_ACT_I64)
+        AQUA_TAB_LAUNCH(AQUA_ACT_F32X2)
+        AQUA_TAB_LAUNCH(AQUA_ACT_SAMPLE_D)
+        AQUA_TAB_LAUNCH(AQUA_ACT_SAMPLE_C)
+        AQUA_TAB_LAUNCH(AQUA_ACT_BEARING)
+        default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
+    }
+#undef AQUA_TAB_LAUNCH
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "aqua_step_tables_f32 launch");
+}
+
+int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, int64_t tld, int64_t N, int64_t env_offset,
+                          float* state, int64_t ld, int32_t* time, const uint8_t* mask, uint64_t seed, uint64_t tick,
+                          const uint64_t* tick_base_dev, void* stream)
+{
+    StepArgs a;
+    const int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(reset_tables_kernel, dim3(grid_for(N, BLOCK_SMALL, 2048)), dim3(BLOCK_SMALL), 0,
+                       static_cast<hipStream_t>(stream), a, mask, tab32_dev, tld);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "aqua_reset_tables_f32 launch");
 }
 
 int aqua_obs_norm_f32(const float* state, int64_t ld, int64_t N, const uint8_t* mask, float* obs_norm, void* stream)

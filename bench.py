@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the done-mask exchange (side stream, double buffer) even on one GPU: rehearsal of the N > 1 path")
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel and a 16M-world point")
+    ap.add_argument("--per-world-tables", action="store_true",
+                    help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
     return ap.parse_args()
 
 
@@ -208,6 +210,8 @@ def main():
             result["cpu_baseline_c"] = c
         if args.extras and world == 1:
             result["extras"] = extras(env, torch, n, a_bytes)
+        if args.per_world_tables and world == 1:
+            result.setdefault("extras", {})["per_world_tables"] = per_world_tables(torch, np, presets, BatchedAqua, n, dev)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -230,6 +234,36 @@ def committed_traffic(n, args):
     if not row:
         return None
     return 2.0 * row["FETCH_SIZE_per_launch_raw"] * 1024.0 + row["WRITE_SIZE_per_launch_raw"] * 1024.0
+
+
+def per_world_tables(torch, np, presets, BatchedAqua, n, dev):
+    """separate line: every world with its own obstacle list (BENCH8, each obstacle moved by up to +-3 units per
+    world), one step launch + one masked-reset launch per step in a HIP graph of 100 steps.  Algorithmic bytes per
+    world-step: 62 + 24 per obstacle row read (6 float32 per row)."""
+    rng = np.random.RandomState(7)
+    tables = np.repeat(presets.BENCH8[None], n, axis=0).astype(np.float64)
+    tables[:, :, 0:2] += rng.uniform(-3, 3, (n, 8, 2))
+    env = BatchedAqua(n, obstacles=tables, seed=0, auto_reset=False, device=dev)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(99)
+    actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=g, dtype=torch.int64).to(torch.uint8)
+    graph = env.capture_steps_per_world(CHUNK, actions)
+    for _ in range(3):
+        graph.launch()
+    torch.cuda.synchronize()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        graph.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * CHUNK)
+    a_bytes = A_DISCRETE + 24 * 8
+    return {"env_steps_per_s": n / us * 1e6, "us_per_step": us, "launches_per_step": 2,
+            "algorithmic_bytes_per_world_step": a_bytes, "achieved_GBps": a_bytes * n / us / 1e3,
+            "frac_of_8TBps": a_bytes * n / us / 1e3 / HBM_PEAK_GBPS,
+            "note": "per-world obstacle tables [K][6][N] float32, restart by a masked reset launch after every step"}
 
 
 def extras(env, torch, n, a_bytes):

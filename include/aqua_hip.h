@@ -156,6 +156,32 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
                            int64_t out_step_stride, int auto_reset, void* stream);
 
 /*
+ * Per-world obstacle tables: every world of the batch has its own obstacle list, as every env object of the
+ * reference has (AquaEnv(obstacles=[...]), aqua.py:13,56-68) -- domain randomisation over a batch.
+ *
+ * aqua_pack_tables() converts rows[N][K][5] float64 (the reference's format, cx, cy, kind 0 circle | 1 rectangle,
+ * a, b; kind < 0 marks an absent row, so worlds may hold fewer than K obstacles) into the two device-format arrays,
+ * on the HOST; the caller uploads them:
+ *   tab32  float32 [K][6][tld]  (cx, cy, hx, hy, R^2, w) per row, struct of arrays over the worlds (coalesced)
+ *   tab64  float64 [K][5][tld]  the rows as given, for the float64 knife-edge path
+ * and returns the largest collision radius of the batch in *r_max (sizes the knife-edge bands).
+ *
+ * aqua_step_tables_f32 / aqua_reset_tables_f32 are aqua_step_f32 (auto_reset = AQUA_RESET_NONE) / aqua_reset_f32 with
+ * these tables; all other arguments mean what they mean there.  Results for a batch whose worlds all hold the
+ * same list are bit-identical to the shared-table calls.  Algorithmic bytes per world-step: 62 + 24 K (discrete).
+ */
+int aqua_pack_tables(const double* rows, int K, int64_t N, int64_t tld, float* tab32_host, double* tab64_host,
+                     float* r_max);
+int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                         float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time,
+                         const void* action, int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld,
+                         uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                         uint64_t* done_bits, float* obs_norm, void* stream);
+int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, int64_t tld, int64_t N, int64_t env_offset,
+                          float* state, int64_t ld, int32_t* time, const uint8_t* mask, uint64_t seed, uint64_t tick,
+                          const uint64_t* tick_base_dev, void* stream);
+
+/*
  * obs_norm[5][ld] <- the observation of `state` scaled as the reference's AquaStateNormalizer
  * (main/impl/utils.py:15-33): what the step kernels' obs_norm epilogue writes, for the worlds a reset just
  * placed (mask as in aqua_reset_f32; NULL: all N).

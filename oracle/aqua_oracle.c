@@ -256,6 +256,34 @@ void aqua_oracle_step(int64_t n, int K, const double* obst, int waves, double* s
     }
 }
 
+/*
+ * The same with one obstacle list PER WORLD (each env object of the reference has its own, aqua.py:13,56-68):
+ * obst_all [n][K][5], rows with kind < 0 are absent.
+ */
+void aqua_oracle_step_tables(int64_t n, int K, const double* obst_all, int waves, double* state, int32_t* time,
+                             int action_kind, const void* action, const double* noise_u, uint64_t seed, uint64_t tick,
+                             int64_t env_offset, double* reward, uint8_t* term, double* margins)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double s[7], u[2], m[3], vl, vr, mine[64 * 5];
+        int Ki = 0;
+        for (int k = 0; k < K && k < 64; ++k) {
+            const double* o = obst_all + (i * K + k) * 5;
+            if (o[2] < 0.0) continue;
+            for (int c = 0; c < 5; ++c) mine[5 * Ki + c] = o[c];
+            ++Ki;
+        }
+        for (int j = 0; j < 7; ++j) s[j] = state[j * n + i];
+        if (noise_u) { u[0] = noise_u[i]; u[1] = noise_u[n + i]; }
+        else { uint32_t raw[4]; aqua_oracle_step_noise(seed, (uint64_t)(env_offset + i), tick, u, raw); }
+        decode_action(action_kind, action, i, n, &vl, &vr);
+        step_one(Ki, mine, waves, s, &time[i], vl, vr, u, &reward[i], &term[i], margins ? m : NULL);
+        for (int j = 0; j < 7; ++j) state[j * n + i] = s[j];
+        if (margins) { margins[i] = m[0]; margins[n + i] = m[1]; margins[2 * n + i] = m[2]; }
+    }
+}
+
 /* ----------------------------------------------------------- reset, float32 */
 /*
  * This build's reset specification (reference behaviour: aqua.py:100-126,442-455 -- rejection
@@ -297,6 +325,46 @@ static int hit_f32(int K, const ObstF* t, float px, float py)
 #define RESET_TRIES 64
 #define KMAX 64
 
+static void reset_world(int K, const ObstF* t, int waves, int random_boat, int random_goal, uint64_t seed, uint64_t tick,
+                        uint64_t env, float* state, int64_t ld, int64_t i, int32_t* time)
+{
+    const float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    uint32_t r[4];
+    float gx = 25.0f, gy = 80.0f;
+    if (random_goal) {
+        for (uint32_t a = 0; a < RESET_TRIES; ++a) {
+            aqua_draw(seed, env, tick, STREAM_PLACE, a, r);
+            float cx = fmaf(95.0f, u01f(r[0]), 2.5f);
+            float cy = fmaf(95.0f, u01f(r[1]), 2.5f);
+            if (!hit_f32(K, t, cx, cy)) { gx = cx; gy = cy; break; }
+        }
+    }
+    aqua_draw(seed, env, tick, STREAM_POSE, 0, r);          /* heading and wave: independent of acceptance */
+    float W = 0.05f * (float)waves;
+    float heading = fmaf(TWO_PI_F, u01f(r[0]), -PI_F);
+    float wx = W * (float)u_pm1(r[1]);
+    float wy = W * (float)u_pm1(r[2]);
+    float bx = 85.0f, by = 45.0f, bt = 0.0f;
+    if (random_boat) {
+        for (uint32_t a = 0; a < RESET_TRIES; ++a) {
+            aqua_draw(seed, env, tick, STREAM_PLACE, a, r);
+            float cx = fmaf(95.0f, u01f(r[2]), 2.5f);
+            float cy = fmaf(95.0f, u01f(r[3]), 2.5f);
+            float ex = gx - cx, ey = gy - cy;
+            float ey2 = ey * ey;
+            float g2 = fmaf(ex, ex, ey2);
+            if (g2 <= 25.0f) continue;                       /* on the goal: aqua.py:112 */
+            if (hit_f32(K, t, cx, cy)) continue;
+            bx = cx; by = cy; bt = heading;
+            break;
+        }
+    }
+    state[0 * ld + i] = bx; state[1 * ld + i] = by; state[2 * ld + i] = bt;
+    state[3 * ld + i] = gx; state[4 * ld + i] = gy;
+    state[5 * ld + i] = wx; state[6 * ld + i] = wy;
+    time[i] = 0;
+}
+
 void aqua_oracle_reset(int64_t n, int K, const double* obst, int waves, int random_boat, int random_goal,
                        uint64_t seed, uint64_t tick, int64_t env_offset, const uint8_t* mask, float* state,
                        int64_t ld, int32_t* time)
@@ -304,45 +372,33 @@ void aqua_oracle_reset(int64_t n, int K, const double* obst, int waves, int rand
     ObstF t[KMAX];
     if (K > KMAX) K = KMAX;
     obst_to_f32(K, obst, 2.5, t);           /* goal radius == boat radius == 2.5 (aqua.py:72,75) */
-    const float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
 #pragma omp parallel for schedule(static) if (n > 4096)
     for (int64_t i = 0; i < n; ++i) {
         if (mask && !mask[i]) continue;
-        uint64_t env = (uint64_t)(env_offset + i);
-        uint32_t r[4];
-        float gx = 25.0f, gy = 80.0f;
-        if (random_goal) {
-            for (uint32_t a = 0; a < RESET_TRIES; ++a) {
-                aqua_draw(seed, env, tick, STREAM_PLACE, a, r);
-                float cx = fmaf(95.0f, u01f(r[0]), 2.5f);
-                float cy = fmaf(95.0f, u01f(r[1]), 2.5f);
-                if (!hit_f32(K, t, cx, cy)) { gx = cx; gy = cy; break; }
-            }
+        reset_world(K, t, waves, random_boat, random_goal, seed, tick, (uint64_t)(env_offset + i), state, ld, i, time);
+    }
+}
+
+/* one obstacle list per world: obst_all [n][K][5], rows with kind < 0 are absent */
+void aqua_oracle_reset_tables(int64_t n, int K, const double* obst_all, int waves, int random_boat, int random_goal,
+                              uint64_t seed, uint64_t tick, int64_t env_offset, const uint8_t* mask, float* state,
+                              int64_t ld, int32_t* time)
+{
+    if (K > KMAX) K = KMAX;
+#pragma omp parallel for schedule(static) if (n > 4096)
+    for (int64_t i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        double mine[KMAX * 5];
+        ObstF t[KMAX];
+        int Ki = 0;
+        for (int k = 0; k < K; ++k) {
+            const double* o = obst_all + (i * K + k) * 5;
+            if (o[2] < 0.0) continue;
+            for (int c = 0; c < 5; ++c) mine[5 * Ki + c] = o[c];
+            ++Ki;
         }
-        aqua_draw(seed, env, tick, STREAM_POSE, 0, r);          /* heading and wave: independent of acceptance */
-        float W = 0.05f * (float)waves;
-        float heading = fmaf(TWO_PI_F, u01f(r[0]), -PI_F);
-        float wx = W * (float)u_pm1(r[1]);
-        float wy = W * (float)u_pm1(r[2]);
-        float bx = 85.0f, by = 45.0f, bt = 0.0f;
-        if (random_boat) {
-            for (uint32_t a = 0; a < RESET_TRIES; ++a) {
-                aqua_draw(seed, env, tick, STREAM_PLACE, a, r);
-                float cx = fmaf(95.0f, u01f(r[2]), 2.5f);
-                float cy = fmaf(95.0f, u01f(r[3]), 2.5f);
-                float ex = gx - cx, ey = gy - cy;
-                float ey2 = ey * ey;
-                float g2 = fmaf(ex, ex, ey2);
-                if (g2 <= 25.0f) continue;                       /* on the goal: aqua.py:112 */
-                if (hit_f32(K, t, cx, cy)) continue;
-                bx = cx; by = cy; bt = heading;
-                break;
-            }
-        }
-        state[0 * ld + i] = bx; state[1 * ld + i] = by; state[2 * ld + i] = bt;
-        state[3 * ld + i] = gx; state[4 * ld + i] = gy;
-        state[5 * ld + i] = wx; state[6 * ld + i] = wy;
-        time[i] = 0;
+        obst_to_f32(Ki, mine, 2.5, t);
+        reset_world(Ki, t, waves, random_boat, random_goal, seed, tick, (uint64_t)(env_offset + i), state, ld, i, time);
     }
 }
 

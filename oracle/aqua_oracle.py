@@ -71,6 +71,10 @@ class COracle(object):
                                         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, c_u8, c_f, ctypes.c_int64,
                                         c_i32]
         L.aqua_oracle_reset.restype = None
+        L.aqua_oracle_step_tables.argtypes = L.aqua_oracle_step.argtypes
+        L.aqua_oracle_step_tables.restype = None
+        L.aqua_oracle_reset_tables.argtypes = L.aqua_oracle_reset.argtypes
+        L.aqua_oracle_reset_tables.restype = None
         L.aqua_oracle_rollout_f32.argtypes = [ctypes.c_int64, ctypes.c_int, c_d, ctypes.c_int, ctypes.c_int, c_f,
                                               ctypes.c_int64, c_i32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                               ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, c_f,
@@ -150,6 +154,39 @@ class COracle(object):
         self.lib.aqua_oracle_reset(n, obst.shape[0], _p(obst, ctypes.c_double), int(waves), int(random_boat),
                                    int(random_goal), int(seed), int(tick), int(env_offset), _p(mask, ctypes.c_uint8),
                                    _p(state, ctypes.c_float), state.shape[1], _p(time, ctypes.c_int32))
+
+    def step_tables(self, state, time, action, tables, waves=1, noise_u=None, seed=0, tick=0, env_offset=0):
+        """step() with one obstacle list per world: tables float64 [n][K][5] (kind < 0: absent row)."""
+        assert state.dtype == np.float64 and state.flags.c_contiguous and state.shape[0] == 7
+        n = state.shape[1]
+        tables = np.ascontiguousarray(tables, dtype=np.float64)
+        assert tables.ndim == 3 and tables.shape[0] == n and tables.shape[2] == 5
+        act, kind = self._action(action)
+        reward = np.empty(n, dtype=np.float64)
+        term = np.empty(n, dtype=np.uint8)
+        margins = np.empty((3, n), dtype=np.float64)
+        if noise_u is not None:
+            noise_u = np.ascontiguousarray(noise_u, dtype=np.float64)
+        self.lib.aqua_oracle_step_tables(n, tables.shape[1], _p(tables, ctypes.c_double), int(waves),
+                                         _p(state, ctypes.c_double), _p(time, ctypes.c_int32), kind,
+                                         act.ctypes.data_as(ctypes.c_void_p), _p(noise_u, ctypes.c_double), int(seed),
+                                         int(tick), int(env_offset), _p(reward, ctypes.c_double), _p(term, ctypes.c_uint8),
+                                         _p(margins, ctypes.c_double))
+        return reward, term, margins
+
+    def reset_tables(self, state, time, tables, waves=1, random_boat=True, random_goal=True, seed=0, tick=0,
+                     env_offset=0, mask=None):
+        """reset() with one obstacle list per world (tables float64 [n][K][5])."""
+        assert state.dtype == np.float32 and state.flags.c_contiguous and state.shape[0] == 7
+        n = time.shape[0]
+        tables = np.ascontiguousarray(tables, dtype=np.float64)
+        assert tables.ndim == 3 and tables.shape[0] == n and tables.shape[2] == 5
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.lib.aqua_oracle_reset_tables(n, tables.shape[1], _p(tables, ctypes.c_double), int(waves), int(random_boat),
+                                          int(random_goal), int(seed), int(tick), int(env_offset),
+                                          _p(mask, ctypes.c_uint8), _p(state, ctypes.c_float), state.shape[1],
+                                          _p(time, ctypes.c_int32))
 
     def rollout_f32(self, state, time, steps, obstacles=None, waves=1, continuous=False, actions=None, seed=0,
                     tick0=0, env_offset=0, auto_reset=True):

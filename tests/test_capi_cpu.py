@@ -72,6 +72,31 @@ def test_pack_obstacles_layout(capi):
         capi.pack_obstacles(np.zeros((65, 5)))
 
 
+def test_pack_tables_layout(capi):
+    """per-world tables: struct of arrays over the worlds, absent rows never hit, per-row band scale, r_max."""
+    lib = capi.lib
+    n, K, tld = 5, 3, 8
+    rows = np.zeros((n, K, 5))
+    rows[:, 0] = [30, 40, 0, 10, 0]           # circle, radius 10 -> R = 12.5
+    rows[:, 1] = [60, 70, 1, 8, 6]            # rectangle 8 x 6   -> R = 2.5
+    rows[:, 2] = [0, 0, -1, 0, 0]             # absent
+    rows[3, 0, 3] = 4.0                       # world 3: smaller circle
+    t32 = np.zeros((K, 6, tld), dtype=np.float32)
+    t64 = np.zeros((K, 5, tld), dtype=np.float64)
+    r_max = ctypes.c_float(0)
+    assert lib.aqua_pack_tables(rows.ctypes.data, K, n, tld, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == 0
+    assert r_max.value == 12.5
+    assert np.array_equal(t64[:, :, :n], rows.transpose(1, 2, 0))
+    assert np.all(t32[0, 4, :n] == np.float32([156.25, 156.25, 156.25, 42.25, 156.25]))
+    assert np.all(t32[1, 2, :n] == 4.0) and np.all(t32[1, 3, :n] == 3.0) and np.all(t32[1, 4, :n] == 6.25)
+    assert np.all(t32[2, 4, :n] < -1e38)                                    # absent rows can never be hit
+    assert np.all(t32[0, 5, [0, 1, 2, 4]] == 1.0) and t32[0, 5, 3] > 1.0     # band scale 1 at R_max, > 1 below it
+    assert np.all(t32[1, 5, :n] > 5.0)
+    bad = rows.copy(); bad[0, 0, 2] = 2.0
+    assert lib.aqua_pack_tables(bad.ctypes.data, K, n, tld, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == -1
+    assert lib.aqua_pack_tables(rows.ctypes.data, K, n, 4, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == -1
+
+
 def test_ring_write_validation_without_touching_a_device(capi):
     lib = capi.lib
     buf = (ctypes.c_float * 64)()

@@ -308,6 +308,86 @@ def test_masked_reset_between_steps_does_not_delay_restarts(torch):
     assert np.all((t[placed] == 1) | (t[placed] == -1 - (tick & 1)))      # stepped once (or finished at once)
 
 
+def _random_tables(rng, n, K):
+    """[n][K][5] reference-format rows: circles (radius 2..10) and rectangles (5..15 x 5..15), some rows absent."""
+    t = np.zeros((n, K, 5))
+    t[:, :, 0:2] = rng.uniform(10, 90, (n, K, 2))
+    kind = rng.randint(0, 2, (n, K)).astype(np.float64)
+    t[:, :, 2] = kind
+    t[:, :, 3] = np.where(kind == 0, rng.uniform(2, 10, (n, K)), rng.uniform(5, 15, (n, K)))
+    t[:, :, 4] = np.where(kind == 0, 0.0, rng.uniform(5, 15, (n, K)))
+    t[:, :, 2] = np.where(rng.randint(0, 5, (n, K)) == 0, -1.0, t[:, :, 2])        # ~20 % absent rows
+    return t
+
+
+def test_per_world_tables_equal_the_shared_table_when_all_worlds_hold_the_same_list(torch):
+    """every world gets its own copy of BENCH8 (row order shuffled per world): reset and 30 steps are bit-identical
+    to the shared-table kernels (auto_reset none)."""
+    from aquaticgymenv_amd import presets
+    n = 20000 + 13
+    rng = np.random.RandomState(8)
+    tables = np.stack([presets.BENCH8[rng.permutation(8)] for _ in range(n)])
+    shared = _make(torch, n, presets.BENCH8, seed=321, auto_reset=False)
+    mine = _make(torch, n, tables, seed=321, auto_reset=False)
+    shared.reset(); mine.reset()
+    assert torch.equal(shared.state, mine.state) and torch.equal(shared.time, mine.time)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(30):
+        act = torch.randint(0, 3, (n,), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+        _, r1, t1 = shared.step(act)
+        _, r2, t2 = mine.step(act)
+        assert torch.equal(t1, t2) and torch.equal(r1, r2)
+    assert torch.equal(shared.state, mine.state) and torch.equal(shared.time, mine.time)
+    assert torch.equal(shared.done_mask(), mine.done_mask())
+
+
+@pytest.mark.parametrize("continuous", [False, True])
+def test_per_world_tables_match_the_oracle(torch, oracle, continuous):
+    """one random obstacle list per world (6 rows, some absent): reset bit for bit, steps against the float64
+    oracle with the same per-world lists (termination codes equal, floats within 1e-5), masked reset."""
+    n, K = 60000 + 7, 6
+    rng = np.random.RandomState(99)
+    tables = _random_tables(rng, n, K)
+    env = _make(torch, n, tables, continuous=continuous, seed=2024, auto_reset=False, env_offset=128)
+    env.reset()
+    torch.cuda.synchronize()
+    k_state, k_time = _host_state(env)
+    st = np.zeros((7, n), dtype=np.float32)
+    tt = np.full(n, 7, dtype=np.int32)
+    oracle.reset_tables(st, tt, tables, waves=1, seed=2024, tick=env.RESET_TICK_BASE, env_offset=128)
+    assert np.array_equal(k_state, st) and np.array_equal(k_time, tt)
+    finished = 0
+    for it in range(12):
+        state0, time0 = _host_state(env)
+        tick = env._tick
+        if continuous:
+            act = (0.2 + 0.3 * rng.uniform(size=(2, env.ld))).astype(np.float32)
+            obs, reward, term = env.step(torch.as_tensor(act).cuda(), soa=True)
+            act = np.ascontiguousarray(act[:, :n])
+        else:
+            act = rng.randint(0, 3, n).astype(np.uint8)
+            obs, reward, term = env.step(torch.as_tensor(act).cuda())
+        torch.cuda.synchronize()
+        s64 = np.ascontiguousarray(state0.astype(np.float64))
+        t = np.ascontiguousarray(time0.astype(np.int32))
+        o_rew, o_term, margins = oracle.step_tables(s64, t, act, tables, waves=1, seed=2024, tick=tick, env_offset=128)
+        k_state, k_time = _host_state(env)
+        term_h = term.cpu().numpy()
+        assert np.array_equal(term_h, o_term)
+        assert np.max(np.abs(k_state[0:2] - s64[0:2])) <= TOL and np.max(angle_diff(k_state[2], s64[2])) <= TOL
+        assert np.max(np.abs(k_state[5:7] - s64[5:7])) <= 1e-7 and np.max(np.abs(reward.cpu().numpy() - o_rew)) <= TOL
+        assert np.array_equal(k_time, t)
+        finished += int((o_term != 0).sum())
+        mask = term_h != 0
+        env.reset(mask=torch.as_tensor(mask).cuda())
+        torch.cuda.synchronize()
+        k2, t2 = _host_state(env)
+        st = k_state.copy(); tt = k_time.copy()
+        oracle.reset_tables(st, tt, tables, waves=1, seed=2024, tick=env.RESET_TICK_BASE + it + 1, env_offset=128, mask=mask)
+        assert np.array_equal(k2, st) and np.array_equal(t2, tt)
+    assert finished > n // 20
+
+
 # ------------------------------------------------------------------------------------------------
 # reset
 # ------------------------------------------------------------------------------------------------
