@@ -109,8 +109,9 @@ class BatchedAqua(object):
             self._tab32 = self._tab64 = None
             self._r_max = 0.0
             if self.per_world:
-                if self.auto_reset != 0:
-                    raise ValueError("per-world obstacle tables: auto_reset must be False (reset(mask=term != 0) restarts worlds)")
+                if self.auto_reset == 2:
+                    raise ValueError("per-world obstacle tables: auto_reset is False or 'same_step' (a masked reset launch "
+                                     "behind every step); 'next_step' is the shared-table kernel's")
                 t32 = np.zeros((self.K, 6, self.ld), dtype=np.float32)
                 t64 = np.zeros((self.K, 5, self.ld), dtype=np.float64)
                 r_max = ctypes.c_float(0.0)
@@ -273,6 +274,16 @@ class BatchedAqua(object):
                                                            self._tick, None, self.reward.data_ptr(), self.term.data_ptr(),
                                                            self.done_bits.data_ptr(), self._norm_ptr(), self._stream()),
                             "aqua_step_tables_f32")
+                if self.auto_reset == 1:      # restart what just finished: exactly reset(mask=term), one more launch
+                    _capi.check(_capi.lib.aqua_reset_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self.K,
+                                                                self.ld, n, self.env_offset, self.state.data_ptr(), self.ld,
+                                                                self.time.data_ptr(), self.term.data_ptr(), self.seed,
+                                                                self.RESET_TICK_BASE + self._resets, None, self._stream()),
+                                "aqua_reset_tables_f32")
+                    if self._norm_ptr() is not None:
+                        _capi.check(_capi.lib.aqua_obs_norm_f32(self.state.data_ptr(), self.ld, n, self.term.data_ptr(),
+                                                                self._norm_ptr(), self._stream()), "aqua_obs_norm_f32")
+                    self._resets += 1
             else:
                 _capi.check(_capi.lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
                                                     self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald,

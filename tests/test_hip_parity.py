@@ -341,6 +341,27 @@ def test_per_world_tables_equal_the_shared_table_when_all_worlds_hold_the_same_l
     assert torch.equal(shared.done_mask(), mine.done_mask())
 
 
+def test_per_world_tables_same_step_restart_is_a_masked_reset(torch):
+    """auto_reset='same_step' with per-world tables == step() followed by reset(mask=term) by hand, bit for bit."""
+    n, K = 30000 + 5, 5
+    rng = np.random.RandomState(4)
+    tables = _random_tables(rng, n, K)
+    auto = _make(torch, n, tables, seed=66, auto_reset="same_step", normalized_obs=True)
+    hand = _make(torch, n, tables, seed=66, auto_reset=False, normalized_obs=True)
+    auto.reset(); hand.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ended = 0
+    for _ in range(25):
+        act = torch.randint(0, 3, (n,), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+        _, r1, t1 = auto.step(act)
+        _, r2, t2 = hand.step(act)
+        hand.reset(mask=t2)
+        assert torch.equal(t1, t2) and torch.equal(r1, r2)
+        ended += int((t1 != 0).sum())
+    assert torch.equal(auto.state, hand.state) and torch.equal(auto.time, hand.time)
+    assert torch.equal(auto.obs_norm, hand.obs_norm) and ended > n // 10 and int(auto.time[:n].min()) >= 0
+
+
 @pytest.mark.parametrize("continuous", [False, True])
 def test_per_world_tables_match_the_oracle(torch, oracle, continuous):
     """one random obstacle list per world (6 rows, some absent): reset bit for bit, steps against the float64
