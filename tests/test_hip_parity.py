@@ -238,8 +238,8 @@ def test_step_matches_oracle_philox(torch, oracle, vec, n, continuous, obst):
         _compare_with_oracle(torch, oracle, env, state0, time0, a_or, reward.cpu().numpy(), term.cpu().numpy(), tick)
 
 
-@pytest.mark.parametrize("mode", [1, 2], ids=["same_step", "next_step"])
-def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
+@pytest.mark.parametrize("mode,env_offset", [(1, 0), (2, 0), (2, 7)], ids=["same_step", "next_step", "next_step_odd_offset"])
+def test_sampled_actions_match_oracle_rollout(torch, oracle, mode, env_offset):
     """device-sampled actions + restart of finished worlds, 40 steps, against the oracle's float32-state
     rollout: teacher-forced per step (the oracle restarts from the kernel's state every step).
     mode 1: finished worlds are re-seeded in the launch that finished them; mode 2 (next-step): they are
@@ -247,7 +247,8 @@ def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
     from aquaticgymenv_amd import presets
     n = 8192 + 37
     for continuous in (False, True):
-        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=99, auto_reset=mode)
+        # (an odd env_offset puts the two worlds of a Philox pair on lanes 2i + 1, 2i + 2: the per-lane fallback)
+        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=99, auto_reset=mode, env_offset=env_offset)
         env.reset()
         finished = 0
         for it in range(40):
@@ -259,7 +260,7 @@ def test_sampled_actions_match_oracle_rollout(torch, oracle, mode):
             tt = t0.copy()
             ep, o_rew, o_term, counts = oracle.rollout_f32(st, tt, 1, obstacles=env.obstacle_rows, waves=1,
                                                             continuous=continuous, seed=env.seed, tick0=tick,
-                                                            auto_reset=mode)
+                                                            env_offset=env_offset, auto_reset=mode)
             k_state, k_time = _host_state(env)
             term_h, rew_h = term.cpu().numpy(), reward.cpu().numpy()
             assert np.array_equal(term_h, o_term)
