@@ -901,31 +901,77 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 
 // ------------------------------------------------------------------ T steps in one launch
 // State stays in registers for the whole rollout; per world-step only the action is read and reward/term
-// are written.  Finished worlds are re-seeded inside the wavefront: the lanes that need it are handed, eight
-// at a time, to the eight 8-lane groups of the wavefront (reset_env_group) and get their fresh state back by
-// shuffle.  Both restart conventions are supported and give exactly the per-step kernels' results.
-__device__ __forceinline__ void wave_reseed(EnvState& e, bool need, const StepArgs& a, const StepConst& k, uint64_t tick,
-                                            int64_t wave_first_world)
+// are written.  Finished worlds are re-seeded once per step for the whole 256-world block: every wavefront
+// publishes its lanes that need it on an LDS list, ONE wavefront (a different one every step) re-seeds them eight
+// lanes per world (reset_env_group) and leaves the fresh states in LDS, the owners pick them up -- two
+// barriers per step.  (Re-seeding inside each wavefront costs a full pass of ~500 instructions in three of
+// four wavefronts per step for one or two worlds each; per block it is one pass for about five.)  In the
+// next-step mode the other wavefronts step their worlds between the two barriers.  Both restart conventions
+// give exactly the per-step kernels' results.
+struct RolloutShared {
+    uint32_t count[2][BLOCK_SMALL / 64];
+    uint8_t list[2][BLOCK_SMALL / 64][64];
+    float result[BLOCK_SMALL][8];
+};
+
+struct ReseedTicket {       // what publish_reseed() hands to collect_reseed()
+    uint32_t n, slot;       // worlds of the block to re-seed (block-uniform); this lane's slot when it is one of them
+};
+
+__device__ __forceinline__ ReseedTicket publish_reseed(bool need, RolloutShared& sh, int parity)
 {
-    const int lane = threadIdx.x & 63;
-    uint64_t m = __ballot(need);
-    while (m != 0) {
-        int owner = -1, src = lane;
-        bool mine = false;
+    constexpr int WAVES = BLOCK_SMALL / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t m = __ballot(need);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    if (need) sh.list[parity][wave][pos] = static_cast<uint8_t>(threadIdx.x);
+    if (lane == 0) sh.count[parity][wave] = static_cast<uint32_t>(__builtin_popcountll(m));
+    __syncthreads();
+    uint32_t first = 0, total = 0;
 #pragma unroll
-        for (int g = 0; g < 64 / RESET_GROUP; ++g) {
-            const int o = m ? static_cast<int>(__builtin_ctzll(m)) : -1;
-            if (lane / RESET_GROUP == g) owner = o;
-            if (o == lane) { src = g * RESET_GROUP; mine = true; }
-            m &= m - 1;
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = sh.count[parity][w];
+        if (w < wave) first += c;
+        total += c;
+    }
+    return ReseedTicket{uni(total), first + pos};
+}
+
+// the duty wavefront re-seeds the published worlds (tick: the tick whose draws the restart uses)
+__device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepArgs& a, const StepConst& k, uint64_t tick,
+                                             int64_t block_first_world, RolloutShared& sh, int parity)
+{
+    constexpr int WAVES = BLOCK_SMALL / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (tk.n == 0 || wave != static_cast<int>(tick & (WAVES - 1))) return;
+    uint32_t first[WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.count[parity][w];
+    constexpr uint32_t PER_PASS = 64 / RESET_GROUP;
+    for (uint32_t qb = 0; qb < tk.n; qb += PER_PASS) {
+        const uint32_t q = qb + (lane / RESET_GROUP);
+        const bool active = q < tk.n;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+        const uint32_t owner = sh.list[parity][seg][active ? q - first[seg] : 0];
+        const EnvState f = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + block_first_world) + owner,
+                                                        tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        if (active && (lane & (RESET_GROUP - 1)) == 0) {
+            float* r = sh.result[q];
+            r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
         }
-        const bool active = owner >= 0;
-        const uint64_t env = static_cast<uint64_t>(a.env_offset + wave_first_world) + static_cast<uint64_t>(active ? owner : 0);
-        const EnvState f = reset_env_group<RESET_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K,
-                                                        k.obst);
-        const float fx = __shfl(f.x, src), fy = __shfl(f.y, src), fth = __shfl(f.th, src), fgx = __shfl(f.gx, src),
-                    fgy = __shfl(f.gy, src), fwx = __shfl(f.wx, src), fwy = __shfl(f.wy, src);
-        if (mine) { e.x = fx; e.y = fy; e.th = fth; e.gx = fgx; e.gy = fgy; e.wx = fwx; e.wy = fwy; e.t = 0; }
+    }
+}
+
+__device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const ReseedTicket& tk, RolloutShared& sh)
+{
+    if (tk.n == 0) return;                               // block-uniform
+    __syncthreads();
+    if (need) {
+        const float* r = sh.result[tk.slot];
+        e.x = r[0]; e.y = r[1]; e.th = r[2]; e.gx = r[3]; e.gy = r[4]; e.wx = r[5]; e.wy = r[6]; e.t = 0;
     }
 }
 
@@ -933,13 +979,14 @@ template <int AK>
 __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
+    __shared__ RolloutShared sh;
     const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
-    // whole wavefronts iterate together (ballots and shuffles inside); lanes past N are inert
-    for (int64_t wbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + (threadIdx.x & ~63); wbase < N;
-         wbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
-        const int64_t i = wbase + (threadIdx.x & 63);
+    // whole blocks iterate together (barriers inside); lanes past N are inert
+    for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
+         bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+        const int64_t i = bbase + threadIdx.x;
         const bool valid = i < N;
         const int64_t ic = valid ? i : N - 1;
         EnvState e{a.state[0 * ld + ic], a.state[1 * ld + ic], a.state[2 * ld + ic], a.state[3 * ld + ic],
@@ -947,17 +994,17 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
         const uint64_t env = static_cast<uint64_t>(a.env_offset + i);        // the lane's own index (pairs of lanes draw together)
         for (int64_t s = 0; s < a.T; ++s) {
             const uint64_t tick = tick0 + static_cast<uint64_t>(s);
+            const int parity = static_cast<int>(s & 1);
             // next-step restart, with the markers of step_ns_kernel: a world that finished last tick does not
             // move this tick, it is re-seeded instead; any other marker waits
-            bool pending = false;
+            bool pending = false, restart = false;
+            ReseedTicket tk{0u, 0u};
             if (a.auto_reset == AQUA_RESET_NEXT_STEP) {
                 if (e.t == restart_code(tick - 1)) e.t = 0;
-                const bool restart = valid && e.t == done_code(tick - 1);
+                restart = valid && e.t == done_code(tick - 1);
                 pending = valid && e.t < 0;
-                if (__any(restart)) {
-                    wave_reseed(e, restart, a, k, tick, wbase);
-                    if (restart) e.t = restart_code(tick);
-                }
+                tk = publish_reseed(restart, sh, parity);
+                serve_reseed(tk, a, k, tick, bbase, sh, parity);     // one wavefront; the others go on stepping
             }
             int idx = 2;
             float vl = 0.5f, vr = 0.5f;
@@ -998,8 +1045,15 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
                 a.term[s * a.out_step_stride + i] = static_cast<uint8_t>(code);
             }
             const bool done = valid && code != 0u;
-            if (a.auto_reset == AQUA_RESET_SAME_STEP) { if (__any(done)) wave_reseed(e, done, a, k, tick, wbase); }
-            else if (a.auto_reset == AQUA_RESET_NEXT_STEP && done) e.t = done_code(tick);
+            if (a.auto_reset == AQUA_RESET_NEXT_STEP) {
+                collect_reseed(e, restart, tk, sh);
+                if (restart) e.t = restart_code(tick);
+                else if (done) e.t = done_code(tick);
+            } else if (a.auto_reset == AQUA_RESET_SAME_STEP) {
+                const ReseedTicket t1 = publish_reseed(done, sh, parity);
+                serve_reseed(t1, a, k, tick, bbase, sh, parity);
+                collect_reseed(e, done, t1, sh);
+            }
         }
         if (valid) {
             a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
