@@ -1,0 +1,21 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from aquaticgymenv_amd import presets
+from aquaticgymenv_amd.batched import BatchedAqua
+for cont in (False, True):
+    env = BatchedAqua(262144, obstacles=presets.BENCH8, seed=5, auto_reset="next_step", continuous=cont, device="cuda:0")
+    env.reset()
+    g = env.capture_rollout(100, actions="random", keep_all=False)
+    t0 = time.time()
+    for rep in range(1000):
+        g.launch()
+    torch.cuda.synchronize()
+    n = env.num_envs
+    st, tm = env.state[:, :n], env.time[:n]
+    last = env._tick - 1
+    neg = tm[tm < 0]
+    ok = bool(((neg == -1 - (last & 1)) | (neg == -3 - (last & 1))).all()) and bool(torch.isfinite(st).all()) \
+        and float(st[0:2].min()) >= 1.5 and float(st[0:2].max()) <= 98.5 and int(tm.max()) <= 1000
+    print("continuous" if cont else "discrete", "100000 steps in %.2f s, invariants %s, pending now %d" % (time.time() - t0, ok, int((tm < 0).sum())))
+    assert ok
