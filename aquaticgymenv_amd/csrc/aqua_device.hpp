@@ -51,6 +51,34 @@ struct ObstHeader {
 };
 static_assert(sizeof(ObstHeader) == 32, "ObstHeader");
 
+// Quick table (tables of at most QUICK_MAX rows; behind the float64 rows, 64-byte aligned): the operands of the first
+// look once more, struct-of-arrays in groups of four obstacles -- circles {cx[4] cy[4] r2[4]}, rectangles
+// {cx[4] cy[4] hx[4] hy[4] r2[4]} -- so that a group is three (five) s_load_dwordx4 at constant offsets from the blob
+// and its SGPR pairs feed v_pk_* operations as they are.  Walking the ObstF rows instead costs a 64-bit address per
+// row, three loads per row and SGPR shuffles to pair the operands: ~110 scalar instructions and four or five
+// scalar-memory round trips per wavefront for 4 circles + 4 rectangles, on a path whose scalar issue is as loaded as
+// its vector issue.  Unused slots hold r2 = -1e30: their margin d^2 + 1e30 never is the
+// minimum, is never inside a band and is never negative.  Same operations in the same order per obstacle as the row
+// loops: the first look's margins have the same bits either way.
+constexpr int QUICK_MAX = 8;
+constexpr float QUICK_EMPTY_R2 = -1.0e30f;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using QuickPtr = const f32x4 __attribute__((address_space(4)))*;
+// in f32x4 units from the start of the quick table: circle groups c0 c1 (64 B each, 3 vectors used), rectangle
+// groups r0 r1 (128 B each, 5 vectors used)
+constexpr int QUICK_C0 = 0, QUICK_C1 = 4, QUICK_R0 = 8, QUICK_R1 = 16, QUICK_VECS = 24;
+__host__ __device__ constexpr size_t quick_offset(int K)
+{
+    return (32u + 72u * static_cast<size_t>(K) + 63u) & ~static_cast<size_t>(63);
+}
+struct QuickCircles { f32x4 cx, cy, r2; };
+struct QuickRects { f32x4 cx, cy, hx, hy, r2; };
+__device__ __forceinline__ QuickCircles quick_circles(QuickPtr q, int at) { return QuickCircles{q[at], q[at + 1], q[at + 2]}; }
+__device__ __forceinline__ QuickRects quick_rects(QuickPtr q, int at)
+{
+    return QuickRects{q[at], q[at + 1], q[at + 2], q[at + 3], q[at + 4]};
+}
+
 // Where the per-batch obstacle table is read from.  Default: straight from the packed blob through the
 // CONSTANT address space -- every lane reads the same row, so the loads are scalar (s_load_dwordx4 into
 // SGPRs, served by the scalar cache) and the rows cost no VGPRs, no LDS round trip and no barrier.
@@ -78,6 +106,9 @@ struct StepConst {              // wave-uniform
     float band2, band2_tight;
     uint32_t touch[4];          // one word per table cache line (see make_const): dependencies, not data
     ObstPtr obst;               // float32 table (scalar-loaded from the blob, or the LDS copy)
+    QuickPtr quick;             // quick table (K <= QUICK_MAX), else unused
+    QuickCircles qc0;           // its first circle / rectangle group, loaded with the header (fast_step<.., QUICK>)
+    QuickRects qr0;
     const double* obst64;       // global float64 rows [K][5] (exact path)
 };
 
@@ -448,7 +479,28 @@ __device__ __forceinline__ ExactOut exact_step_world(float fx, float fy, float f
 // which is inside the band by construction.
 // PER_WORLD: the obstacle rows come from this lane's own table (`wt`, generic box formula for every row) instead of
 // the batch's shared one.
-template <bool PER_WORLD = false>
+__device__ __forceinline__ float quick_min(float mo, float xn, float yn, const QuickCircles& g)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dx = xn - g.cx[j], dy = yn - g.cy[j];
+        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -g.r2[j])));
+    }
+    return mo;
+}
+__device__ __forceinline__ float quick_min(float mo, float xn, float yn, const QuickRects& g)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dx = fmaxf(fabsf(xn - g.cx[j]) - g.hx[j], 0.0f);
+        const float dy = fmaxf(fabsf(yn - g.cy[j]) - g.hy[j], 0.0f);
+        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -g.r2[j])));
+    }
+    return mo;
+}
+
+// QUICK: the first look reads the quick table (k.qc0, k.qr0, k.quick) instead of walking the rows.
+template <bool PER_WORLD = false, bool QUICK = false>
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
                                           const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr)
 {
@@ -472,6 +524,16 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
             const float dx = fmaxf(fabsf(xn - r.cx) - r.hx, 0.0f);
             const float dy = fmaxf(fabsf(yn - r.cy) - r.hy, 0.0f);
             mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -r.r2)));
+        }
+    } else if constexpr (QUICK) {
+        const int nr = k.K - k.Kc;
+        if (k.Kc > 0) {
+            mo = quick_min(mo, xn, yn, k.qc0);
+            if (k.Kc > 4) mo = quick_min(mo, xn, yn, quick_circles(k.quick, QUICK_C1));
+        }
+        if (nr > 0) {
+            mo = quick_min(mo, xn, yn, k.qr0);
+            if (nr > 4) mo = quick_min(mo, xn, yn, quick_rects(k.quick, QUICK_R1));
         }
     } else {
 #pragma unroll 2

@@ -207,6 +207,7 @@ __device__ __forceinline__ ObstPtr stage_obstacles(ObstF*, const void* blob, int
 }
 #endif
 
+template <bool QUICK = false>
 __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
 {
     StepConst k;
@@ -230,7 +231,16 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
         // at a time -- each of them would otherwise be a miss of its own, one memory round trip after the other.
         // Four independent loads, unconditional: a packed blob is never shorter than AQUA_BLOB_MIN_BYTES.
         const uint32_t __attribute__((address_space(4)))* w = (const uint32_t __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
-        k.touch[0] = w[16]; k.touch[1] = w[32]; k.touch[2] = w[48]; k.touch[3] = w[64];
+        if constexpr (QUICK) {
+            // The first look reads the quick table, not the rows: its first two groups go out with the header (one
+            // scalar-memory round trip for everything, in the shadow of the state loads and the draws) and are the
+            // lines worth having; the rows are left to the second look and the float64 path.
+            k.quick = (QuickPtr)(uintptr_t)(reinterpret_cast<const char*>(a.obst_blob) + quick_offset(a.K));
+            k.qc0 = quick_circles(k.quick, QUICK_C0);
+            k.qr0 = quick_rects(k.quick, QUICK_R0);
+        } else {
+            k.touch[0] = w[16]; k.touch[1] = w[32]; k.touch[2] = w[48]; k.touch[3] = w[64];
+        }
     }
     k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstHeader) +
                                                sizeof(ObstF) * a.K);
@@ -660,6 +670,9 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
 #ifndef AQUA_NS_MAIN_WAVES
 #define AQUA_NS_MAIN_WAVES 4
 #endif
+#ifndef AQUA_NS_QUICK                       // 1: stepping blocks read the quick table (tables of up to 8 rows); 0: the rows
+#define AQUA_NS_QUICK 1
+#endif
 #ifndef AQUA_NS_SCAN_ROWS
 #define AQUA_NS_SCAN_ROWS 4
 #endif
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
         avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
     }
-    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<SMALL_TABLE && AQUA_NS_QUICK>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick = launch_tick(a);
     AQUA_RTSTAMP(0);
     // The draws need no loaded value: they run in the shadow of the loads.
@@ -864,9 +877,9 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     AQUA_RTSTAMP(1);
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
 #ifdef AQUA_EXP_NO_EXACT                   // timing experiment only: what the float64 path costs the launch
-    const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live && false;
+    const bool knife = fast_step<false, SMALL_TABLE && AQUA_NS_QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live && false;
 #else
-    const bool knife = fast_step(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
+    const bool knife = fast_step<false, SMALL_TABLE && AQUA_NS_QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
 #endif
     if (__builtin_expect(__any(knife) != 0, 0)) {
         if (knife) {
@@ -875,6 +888,17 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
             e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
         }
     }
+#ifdef AQUA_EXP_EXTRA_VALU                  // timing experiment only: this many extra independent-ish VALU operations
+    {
+        float acc0 = rew, acc1 = e.x, acc2 = e.y, acc3 = e.th;
+#pragma unroll
+        for (int z = 0; z < AQUA_EXP_EXTRA_VALU / 4; ++z) {
+            acc0 = fmaf(acc0, 1.0000001f, 1.0e-9f); acc1 = fmaf(acc1, 1.0000001f, 1.0e-9f);
+            acc2 = fmaf(acc2, 1.0000001f, 1.0e-9f); acc3 = fmaf(acc3, 1.0000001f, 1.0e-9f);
+        }
+        if (acc0 + acc1 + acc2 + acc3 == 12345.678f) rew = 0.0f;
+    }
+#endif
     if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
     const bool done = code != 0u;
     if (valid) {
@@ -1402,6 +1426,7 @@ size_t aqua_obstacle_blob_bytes(int K)
 {
     if (K <= 0) return 0;
     const size_t used = sizeof(ObstHeader) + static_cast<size_t>(K) * (sizeof(ObstF) + 5 * sizeof(double));
+    if (K <= QUICK_MAX) return quick_offset(K) + QUICK_VECS * sizeof(f32x4);   // header, rows, float64 rows, quick table
     return used < AQUA_BLOB_MIN_BYTES ? AQUA_BLOB_MIN_BYTES : used;     // the kernels touch the first five 64-byte lines
 }
 
@@ -1446,6 +1471,21 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
     h->band2_tight = static_cast<float>(tight(r_max));
     for (int k = 0; k < K; ++k)                          // per-obstacle scale of the compensated margin (ObstF::w)
         f[k].w = static_cast<float>(static_cast<double>(h->band2_tight) / tight(std::sqrt(static_cast<double>(f[k].r2))));
+    if (K <= QUICK_MAX) {                                // quick table: the first look's operands, four obstacles per group
+        float* q = reinterpret_cast<float*>(static_cast<char*>(blob_host) + quick_offset(K));
+        const auto group = [&](int vec0, int j) { return q + 4 * vec0 + (j & 3); };      // + 4 * field
+        for (int j = 0; j < QUICK_MAX; ++j) {
+            float* c = group(j < 4 ? QUICK_C0 : QUICK_C1, j);
+            const bool used = j < n_circles;
+            c[0] = used ? f[j].cx : 0.0f; c[4] = used ? f[j].cy : 0.0f; c[8] = used ? f[j].r2 : QUICK_EMPTY_R2;
+            float* r = group(j < 4 ? QUICK_R0 : QUICK_R1, j);
+            const int row = n_circles + j;
+            const bool have = row < K;
+            r[0] = have ? f[row].cx : 0.0f; r[4] = have ? f[row].cy : 0.0f;
+            r[8] = have ? f[row].hx : 0.0f; r[12] = have ? f[row].hy : 0.0f; r[16] = have ? f[row].r2 : QUICK_EMPTY_R2;
+        }
+        h->reserved[0] = static_cast<int32_t>(quick_offset(K));
+    }
     return 0;
 }
 
