@@ -52,16 +52,16 @@ struct ObstHeader {
 static_assert(sizeof(ObstHeader) == 32, "ObstHeader");
 
 // Quick table (tables of at most QUICK_MAX rows; behind the float64 rows, 64-byte aligned): the operands of the first
-// look once more, struct-of-arrays in groups of four obstacles -- circles {cx[4] cy[4] r2[4]}, rectangles
-// {cx[4] cy[4] hx[4] hy[4] r2[4]} -- so that a group is three (five) s_load_dwordx4 at constant offsets from the blob
+// look once more, struct-of-arrays in groups of four obstacles -- circles {cx[4] cy[4] -r2[4]}, rectangles
+// {cx[4] cy[4] hx[4] hy[4] -r2[4]} -- so that a group is three (five) s_load_dwordx4 at constant offsets from the blob
 // and its SGPR pairs feed v_pk_* operations as they are.  Walking the ObstF rows instead costs a 64-bit address per
 // row, three loads per row and SGPR shuffles to pair the operands: ~110 scalar instructions and four or five
 // scalar-memory round trips per wavefront for 4 circles + 4 rectangles, on a path whose scalar issue is as loaded as
-// its vector issue.  Unused slots hold r2 = -1e30: their margin d^2 + 1e30 never is the
+// its vector issue.  Unused slots hold -r2 = 1e30: their margin d^2 + 1e30 never is the
 // minimum, is never inside a band and is never negative.  Same operations in the same order per obstacle as the row
 // loops: the first look's margins have the same bits either way.
 constexpr int QUICK_MAX = 8;
-constexpr float QUICK_EMPTY_R2 = -1.0e30f;
+constexpr float QUICK_EMPTY_NR2 = 1.0e30f;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 using QuickPtr = const f32x4 __attribute__((address_space(4)))*;
 // in f32x4 units from the start of the quick table: circle groups c0 c1 (64 B each, 3 vectors used), rectangle
@@ -71,8 +71,8 @@ __host__ __device__ constexpr size_t quick_offset(int K)
 {
     return (32u + 72u * static_cast<size_t>(K) + 63u) & ~static_cast<size_t>(63);
 }
-struct QuickCircles { f32x4 cx, cy, r2; };
-struct QuickRects { f32x4 cx, cy, hx, hy, r2; };
+struct QuickCircles { f32x4 cx, cy, nr2; };                 // nr2 = -R^2: the fma's addend as it is
+struct QuickRects { f32x4 cx, cy, hx, hy, nr2; };
 __device__ __forceinline__ QuickCircles quick_circles(QuickPtr q, int at) { return QuickCircles{q[at], q[at + 1], q[at + 2]}; }
 __device__ __forceinline__ QuickRects quick_rects(QuickPtr q, int at)
 {
@@ -169,19 +169,20 @@ __device__ __forceinline__ uint32_t swap_pair(uint32_t v)
 __device__ __forceinline__ void philox4x32_10_pair(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
                                                    uint32_t c3, bool odd, uint32_t& w0, uint32_t& w1)
 {
-    uint32_t a = odd ? c2 : c0, b = odd ? c3 : c1, key = odd ? k1 : k0;
+    // m: this lane's multiplicand (c0 | c2).  p: the PARTNER's other word (even lane: c3, odd lane: c1) -- it is only
+    // ever combined with this lane's next high word, so it stays here and one value crosses per round, not two.
+    uint32_t m = odd ? c2 : c0, p = odd ? c1 : c3, key = odd ? k1 : k0;
     const uint32_t mult = odd ? 0xCD9E8D57u : 0xD2511F53u;
     const uint32_t bump = odd ? 0xBB67AE85u : 0x9E3779B9u;
 #pragma unroll
     for (int r = 0; r < AQUA_PHILOX_ROUNDS; ++r) {
-        const uint64_t p = static_cast<uint64_t>(a) * mult;
-        const uint32_t other_hi = swap_pair(static_cast<uint32_t>(p >> 32));
-        const uint32_t other_lo = swap_pair(static_cast<uint32_t>(p));
-        a = other_hi ^ b ^ key;          // even: hi(M1 c2) ^ c1 ^ k0    odd: hi(M0 c0) ^ c3 ^ k1
-        b = other_lo;                    // even: lo(M1 c2)              odd: lo(M0 c0)
+        const uint64_t prod = static_cast<uint64_t>(m) * mult;
+        const uint32_t t = static_cast<uint32_t>(prod >> 32) ^ p;   // odd: hi(M1 c2) ^ c1     even: hi(M0 c0) ^ c3
+        m = swap_pair(t) ^ key;                                     // even: .. ^ k0 = c0'     odd: .. ^ k1 = c2'
+        p = static_cast<uint32_t>(prod);                            // odd: lo(M1 c2) = c1'    even: lo(M0 c0) = c3'
         key += bump;
     }
-    w0 = a; w1 = b;
+    w0 = m; w1 = swap_pair(p);
 }
 
 __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, uint32_t attempt,
@@ -479,12 +480,15 @@ __device__ __forceinline__ ExactOut exact_step_world(float fx, float fy, float f
 // which is inside the band by construction.
 // PER_WORLD: the obstacle rows come from this lane's own table (`wt`, generic box formula for every row) instead of
 // the batch's shared one.
+// Plain one-obstacle operations on purpose.  The packed forms (v_pk_add_f32 / v_pk_fma_f32 on SGPR pairs, two obstacles
+// per operation) and d - v_med3_f32(d, -h, h) for the rectangles' fabs / subtract / max triple are 8 and 12 vector
+// instructions fewer per group and measured 0.07 us per step SLOWER (5.16 vs 5.09).
 __device__ __forceinline__ float quick_min(float mo, float xn, float yn, const QuickCircles& g)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float dx = xn - g.cx[j], dy = yn - g.cy[j];
-        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -g.r2[j])));
+        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, g.nr2[j])));
     }
     return mo;
 }
@@ -494,7 +498,7 @@ __device__ __forceinline__ float quick_min(float mo, float xn, float yn, const Q
     for (int j = 0; j < 4; ++j) {
         const float dx = fmaxf(fabsf(xn - g.cx[j]) - g.hx[j], 0.0f);
         const float dy = fmaxf(fabsf(yn - g.cy[j]) - g.hy[j], 0.0f);
-        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -g.r2[j])));
+        mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, g.nr2[j])));
     }
     return mo;
 }

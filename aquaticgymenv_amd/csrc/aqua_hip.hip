@@ -377,6 +377,19 @@ __device__ __forceinline__ void write_norm(const StepArgs& a, int64_t i, float x
     st1(o + 4 * a.ld, gy * 0.01f);
 }
 
+// the same rows written as uniform row base + the lane's 32-bit byte offset (st_at)
+__device__ __forceinline__ void write_norm_at(const StepArgs& a, int64_t tile, uint32_t byte_off, float x, float y, float th,
+                                              float gx, float gy)
+{
+    if (a.obs_norm == nullptr) return;
+    float* const o = a.obs_norm + tile;
+    st_at(o + 0 * a.ld, byte_off, x * 0.01f);
+    st_at(o + 1 * a.ld, byte_off, y * 0.01f);
+    st_at(o + 2 * a.ld, byte_off, fmaf(th, 0.15915494309189535f, 0.5f));
+    st_at(o + 3 * a.ld, byte_off, gx * 0.01f);
+    st_at(o + 4 * a.ld, byte_off, gy * 0.01f);
+}
+
 // reward / term / packed done bits of one wavefront's worlds
 template <int VEC>
 __device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, bool full,
@@ -901,9 +914,15 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
 #endif
     if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
     const bool done = code != 0u;
+    // The stores' own copies of the lane offset.  With the loads' o4 the seven row addresses are common
+    // subexpressions of the loads' and are kept, as 64-bit VGPR pairs formed by v_lshl_add_u64, from the top of
+    // the block to here; a value the optimiser cannot match to it leaves base + offset to be formed where it is
+    // used, and there it is the store's own SGPR base + 32-bit VGPR offset addressing: no instruction at all.
+    uint32_t s4 = o4, s1 = o;
+    asm volatile("" : "+v"(s4), "+v"(s1));
     if (valid) {
-        st_at(a.reward + tile, o4, rew);
-        st_at(a.term + tile, o, static_cast<uint8_t>(code));
+        st_at(a.reward + tile, s4, rew);
+        st_at(a.term + tile, s1, static_cast<uint8_t>(code));
     }
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done);
@@ -911,14 +930,14 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
     }
     if (live) {                                        // pending worlds are written by the re-seeding blocks
-        st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
-        st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
+        st_at(row0 + 0 * ld, s4, e.x); st_at(row0 + 1 * ld, s4, e.y); st_at(row0 + 2 * ld, s4, e.th);
+        st_at(row0 + 5 * ld, s4, e.wx); st_at(row0 + 6 * ld, s4, e.wy);
 #ifdef AQUA_NS_NOWORK
-        st_at(trow, o4, e.t);
+        st_at(trow, s4, e.t);
 #else
-        st_at(trow, o4, done ? done_code(tick) : e.t);
+        st_at(trow, s4, done ? done_code(tick) : e.t);
 #endif
-        write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
+        write_norm_at(a, tile, s4, e.x, e.y, e.th, gx[0], gy[0]);
     }
     AQUA_RTSTAMP(2);
 }
@@ -1477,12 +1496,12 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
         for (int j = 0; j < QUICK_MAX; ++j) {
             float* c = group(j < 4 ? QUICK_C0 : QUICK_C1, j);
             const bool used = j < n_circles;
-            c[0] = used ? f[j].cx : 0.0f; c[4] = used ? f[j].cy : 0.0f; c[8] = used ? f[j].r2 : QUICK_EMPTY_R2;
+            c[0] = used ? f[j].cx : 0.0f; c[4] = used ? f[j].cy : 0.0f; c[8] = used ? -f[j].r2 : QUICK_EMPTY_NR2;
             float* r = group(j < 4 ? QUICK_R0 : QUICK_R1, j);
             const int row = n_circles + j;
             const bool have = row < K;
             r[0] = have ? f[row].cx : 0.0f; r[4] = have ? f[row].cy : 0.0f;
-            r[8] = have ? f[row].hx : 0.0f; r[12] = have ? f[row].hy : 0.0f; r[16] = have ? f[row].r2 : QUICK_EMPTY_R2;
+            r[8] = have ? f[row].hx : 0.0f; r[12] = have ? f[row].hy : 0.0f; r[16] = have ? -f[row].r2 : QUICK_EMPTY_NR2;
         }
         h->reserved[0] = static_cast<int32_t>(quick_offset(K));
     }

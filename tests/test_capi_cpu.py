@@ -55,9 +55,11 @@ def test_pack_obstacles_layout(capi):
     assert capi.lib.aqua_obstacle_blob_bytes(9) == 32 + 9 * 72 and capi.lib.aqua_obstacle_blob_bytes(2) >= 320
     q = np.frombuffer(blob[quick:], dtype=np.float32).reshape(24, 4)
     rows32 = np.frombuffer(blob[32:32 + k * 32], dtype=np.float32).reshape(k, 8)
-    # circle groups {cx cy r2 -}, rectangle groups {cx cy hx hy r2 - - -}; unused slots: r2 = -1e30, the rest 0
-    assert np.array_equal(q[0:3], rows32[:4, [0, 1, 4]].T) and np.array_equal(q[8:13], rows32[4:, [0, 1, 2, 3, 4]].T)
-    assert np.all(q[6] == np.float32(-1e30)) and np.all(q[20] == np.float32(-1e30)) and np.all(q[4:6] == 0) and np.all(q[16:20] == 0)
+    # circle groups {cx cy -r2 .}, rectangle groups {cx cy hx hy -r2 . . .}; unused slots: -r2 = 1e30, the rest 0
+    sign = np.array([1, 1, 1, 1, -1], dtype=np.float32)[:, None]
+    assert np.array_equal(q[0:3], rows32[:4, [0, 1, 4]].T * sign[[0, 1, 4]])
+    assert np.array_equal(q[8:13], rows32[4:, [0, 1, 2, 3, 4]].T * sign)
+    assert np.all(q[6] == np.float32(1e30)) and np.all(q[20] == np.float32(1e30)) and np.all(q[4:6] == 0) and np.all(q[16:20] == 0)
     assert np.frombuffer(blob[20:24], dtype=np.int32)[0] == quick
     hdr_i = np.frombuffer(blob[:8], dtype=np.int32)
     hdr_f = np.frombuffer(blob[8:16], dtype=np.float32)
