@@ -276,6 +276,10 @@ __device__ __forceinline__ uint64_t uni(uint64_t v)
 {
     return (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
 }
+// "does any active lane ...": the ballot is the compare's own SGPR pair and the test a scalar compare.  (__any()
+// goes through a 0/1 value per lane: v_cndmask + v_cmp on top of the compare.)
+__device__ __forceinline__ bool any_lane(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
+
 template <typename P> __device__ __forceinline__ P uni_ptr(P p) { return (P)uni((uint64_t)(uintptr_t)p); }
 
 // ------------------------------------------------------------------------------------ exact path
@@ -503,8 +507,10 @@ __device__ __forceinline__ float quick_min(float mo, float xn, float yn, const Q
     return mo;
 }
 
-// QUICK: the first look reads the quick table (k.qc0, k.qr0, k.quick) instead of walking the rows.
-template <bool PER_WORLD = false, bool QUICK = false>
+// QUICK: the first look reads the quick table (k.qc0, k.qr0, k.quick) instead of walking the rows --
+// QUICK_ALWAYS: the caller knows the table has one; QUICK_IF_PRESENT: when k.quick is not NULL (wave-uniform).
+enum : int { QUICK_NEVER = 0, QUICK_ALWAYS = 1, QUICK_IF_PRESENT = 2 };
+template <bool PER_WORLD = false, int QUICK = QUICK_NEVER>
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
                                           const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr)
 {
@@ -515,8 +521,13 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float xn = e.x + ddx, yn = e.y + ddy;
     const float thn = wrap_add(e.th, w);
     // wave random walk (aqua.py:188-191): drawn after the move
+#ifdef AQUA_EXP_CLAMP_MINMAX                // timing experiment: v_max + v_min instead of v_med3 (same values)
+    const float wxn = fminf(fmaxf(fmaf(u0, k.sigma, e.wx), -k.W), k.W);
+    const float wyn = fminf(fmaxf(fmaf(u1, k.sigma, e.wy), -k.W), k.W);
+#else
     const float wxn = __builtin_amdgcn_fmed3f(fmaf(u0, k.sigma, e.wx), -k.W, k.W);
     const float wyn = __builtin_amdgcn_fmed3f(fmaf(u1, k.sigma, e.wy), -k.W, k.W);
+#endif
     const int tn = e.t + 1;                                // aqua.py:141
 
     const float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
@@ -529,7 +540,7 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
             const float dy = fmaxf(fabsf(yn - r.cy) - r.hy, 0.0f);
             mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -r.r2)));
         }
-    } else if constexpr (QUICK) {
+    } else if (QUICK == QUICK_ALWAYS || (QUICK == QUICK_IF_PRESENT && k.quick != nullptr)) {
         const int nr = k.K - k.Kc;
         if (k.Kc > 0) {
             mo = quick_min(mo, xn, yn, k.qc0);
@@ -568,7 +579,7 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     knife = false;
 #endif
     float mc_f = mc, mo_f = mo, mg_f = mg;
-    if (__builtin_expect(__any(knife) != 0, 0)) {
+    if (__builtin_expect(any_lane(knife), 0)) {
         // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
         // by the rounding of x' = x + ddx itself (up to 3.8e-6).  Carry the rounding error of that sum
         // (xlo = ddx - (x' - x), exact: FastTwoSum) through the three margins; what is left is the error of
@@ -858,14 +869,14 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
         const int bsrc = bm ? gbase + __builtin_ctzll(bm) : lane;
         const float sbx = __shfl(cbx, bsrc), sby = __shfl(cby, bsrc);
         if (goal_found && !boat_done && !serial && bm) { bx = sbx; by = sby; bt = heading; boat_done = true; }
-        if (!__any((!goal_found || !boat_done) && !serial)) break;
+        if (!any_lane((!goal_found || !boat_done) && !serial)) break;
 #ifdef AQUA_EXP_ONE_ROUND                  // timing experiment only: what the later rounds of the re-seeding cost
         break;
 #endif
     }
     // goal attempts exhausted: the goal stays at its fixed default (aqua.py:107) and the boat is still scanned
     if (active && random_boat && !boat_done && !goal_found) serial = true;
-    if (__builtin_expect(__any(serial) != 0, 0)) {
+    if (__builtin_expect(any_lane(serial), 0)) {
         if (serial && sub == 0) {
             uint32_t rr[4];
             for (uint32_t a = 0; a < RESET_TRIES; ++a) {

@@ -207,10 +207,14 @@ __device__ __forceinline__ ObstPtr stage_obstacles(ObstF*, const void* blob, int
 }
 #endif
 
-template <bool QUICK = false>
+#ifndef AQUA_QUICK_OTHERS                   // the other step kernels: QUICK_IF_PRESENT (2) or QUICK_NEVER (0)
+#define AQUA_QUICK_OTHERS QUICK_IF_PRESENT
+#endif
+template <int QUICK = QUICK_NEVER>
 __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
 {
     StepConst k;
+    k.quick = nullptr;                  // (qc0 / qr0 are read only when quick is set)
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K;
     k.obst = obst;
     k.Kc = 0; k.band2 = 0.0f; k.band2_tight = 0.0f;
@@ -231,14 +235,16 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
         // at a time -- each of them would otherwise be a miss of its own, one memory round trip after the other.
         // Four independent loads, unconditional: a packed blob is never shorter than AQUA_BLOB_MIN_BYTES.
         const uint32_t __attribute__((address_space(4)))* w = (const uint32_t __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
-        if constexpr (QUICK) {
+        if (QUICK == QUICK_ALWAYS || (QUICK == QUICK_IF_PRESENT && a.K <= QUICK_MAX)) {
             // The first look reads the quick table, not the rows: its first two groups go out with the header (one
             // scalar-memory round trip for everything, in the shadow of the state loads and the draws) and are the
             // lines worth having; the rows are left to the second look and the float64 path.
             k.quick = (QuickPtr)(uintptr_t)(reinterpret_cast<const char*>(a.obst_blob) + quick_offset(a.K));
             k.qc0 = quick_circles(k.quick, QUICK_C0);
             k.qr0 = quick_rects(k.quick, QUICK_R0);
-        } else {
+        }
+        // (the next-step kernel's stepping blocks read nothing else of the table outside the rare second look)
+        if constexpr (QUICK != QUICK_ALWAYS) {
             k.touch[0] = w[16]; k.touch[1] = w[32]; k.touch[2] = w[48]; k.touch[3] = w[64];
         }
     }
@@ -270,7 +276,8 @@ __device__ __forceinline__ Motion decode_motion(const StepConst& k, int idx, flo
         thrust_to_motion(cl, cr, m.h, m.w, m.chord);
     } else {
         m.h = idx == 0 ? ACT_H_TURN : (idx == 1 ? -ACT_H_TURN : ACT_H_LINE);
-        m.w = idx == 0 ? ACT_W_TURN : (idx == 1 ? -ACT_W_TURN : ACT_W_LINE);
+        static_assert(ACT_W_TURN == 2.0f * ACT_H_TURN && ACT_W_LINE == 2.0f * ACT_H_LINE, "w = 2 h, exactly");
+        m.w = m.h + m.h;
         m.chord = idx == 2 ? ACT_C_LINE : ACT_C_TURN;
     }
     return m;
@@ -550,7 +557,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         EnvState e{x[j], y[j], th[j], gx[j], gy[j], wx[j], wy[j], t[j]};
         mo[j] = decode_motion<AK>(k, aidx[j], avl[j], avr[j]);
         uint32_t c;
-        const bool knife = fast_step(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
+        const bool knife = fast_step<false, AQUA_QUICK_OTHERS>(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
         const bool valid = static_cast<int64_t>(off) + j < rem;
         knife_mask |= (knife && valid) ? (1u << j) : 0u;
         code[j] = static_cast<uint8_t>(c);
@@ -558,7 +565,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     }
     AQUA_STAMP(2);          // fast path done
     // knife-edge worlds: redo pose, reward and termination in float64 (reference operation order)
-    if (__any(knife_mask != 0)) {
+    if (any_lane(knife_mask != 0)) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (knife_mask & (1u << j)) {
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
     AQUA_OBST_DECL
     __shared__ TileShared sh;
     if (threadIdx.x == 0) sh.count = 0;
-    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<AQUA_QUICK_OTHERS>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     if (a.auto_reset) __syncthreads();
     const uint64_t tick = launch_tick(a);
     step_tile<VEC, AK>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
         avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
         avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
     }
-    const StepConst k = make_const<SMALL_TABLE && AQUA_NS_QUICK>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<(SMALL_TABLE && AQUA_NS_QUICK) ? QUICK_ALWAYS : QUICK_NEVER>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick = launch_tick(a);
     AQUA_RTSTAMP(0);
     // The draws need no loaded value: they run in the shadow of the loads.
@@ -890,11 +897,11 @@ __global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
     AQUA_RTSTAMP(1);
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
 #ifdef AQUA_EXP_NO_EXACT                   // timing experiment only: what the float64 path costs the launch
-    const bool knife = fast_step<false, SMALL_TABLE && AQUA_NS_QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live && false;
+    const bool knife = fast_step<false, (SMALL_TABLE && AQUA_NS_QUICK) ? QUICK_ALWAYS : QUICK_NEVER>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live && false;
 #else
-    const bool knife = fast_step<false, SMALL_TABLE && AQUA_NS_QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
+    const bool knife = fast_step<false, (SMALL_TABLE && AQUA_NS_QUICK) ? QUICK_ALWAYS : QUICK_NEVER>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
 #endif
-    if (__builtin_expect(__any(knife) != 0, 0)) {
+    if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
                                            k.obst, k.band2, k.time_limit);
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
     __shared__ RolloutShared sh;
-    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<AQUA_QUICK_OTHERS>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     // whole blocks iterate together (barriers inside); lanes past N are inert
@@ -1072,8 +1079,8 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
             EnvState after = e;
             float rew;
             uint32_t code;
-            const bool knife = fast_step(after, m.h, m.w, m.chord, u0, u1, k, rew, code) && valid && !pending;
-            if (__any(knife)) {
+            const bool knife = fast_step<false, AQUA_QUICK_OTHERS>(after, m.h, m.w, m.chord, u0, u1, k, rew, code) && valid && !pending;
+            if (any_lane(knife)) {
                 if (knife) {
                     const ExactOut o = exact_step(before.x, before.y, before.th, before.gx, before.gy, before.wx,
                                                   before.wy, after.t, exact_motion<AK>(m), k.K, k.obst64, k.obst, k.band2,
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
     float rew;
     uint32_t code;
     const bool knife = fast_step<true>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt) && valid;
-    if (__builtin_expect(__any(knife) != 0, 0)) {
+    if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step_world(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.band2,
                                                  k.time_limit, wt);
