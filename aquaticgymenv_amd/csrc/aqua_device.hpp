@@ -772,15 +772,19 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 #else
 #define AQUA_RESEED_ATTR __noinline__
 #endif
-// ROWS: the table (ROWS rows, absent ones with r2 < 0) is read from `rows` in LDS, four rows at a time, instead
+// ROWS > 0: the table (ROWS rows, absent ones with r2 < 0) is read from `rows` in LDS, a few rows at a time, instead
 // of through the scalar path, which waits once per two rows.
+// ROWS == RESEED_QUICK: the table is read from its quick table `quick` (Kc circles first): one scalar-memory round trip
+// per group of four obstacles, and the hit tests are the row tests on the same values (a circle's half extents are
+// the zeros they are in its row; r2 = -(-r2)).
 #ifndef AQUA_RESEED_HALF_BARRIER
 #define AQUA_RESEED_HALF_BARRIER 1
 #endif
+constexpr int RESEED_QUICK = -1;
 template <int G, int ROWS = 0>
 __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
-                                                     const ObstF* rows = nullptr)
+                                                     const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0)
 {
 #pragma clang fp contract(off)
     static_assert(G >= 2 && G <= 64 && (G & (G - 1)) == 0, "group size");
@@ -845,6 +849,24 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
 #endif
+            }
+        } else if constexpr (ROWS == RESEED_QUICK) {
+            const auto circles = [&](const QuickCircles& g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) test(g.cx[j], g.cy[j], 0.0f, 0.0f, -g.nr2[j]);
+            };
+            const auto rects = [&](const QuickRects& g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) test(g.cx[j], g.cy[j], g.hx[j], g.hy[j], -g.nr2[j]);
+            };
+            Kc = uni(Kc); quick = uni_ptr(quick);
+            if (Kc > 0) {
+                circles(quick_circles(quick, QUICK_C0));
+                if (Kc > 4) circles(quick_circles(quick, QUICK_C1));
+            }
+            if (K - Kc > 0) {
+                rects(quick_rects(quick, QUICK_R0));
+                if (K - Kc > 4) rects(quick_rects(quick, QUICK_R1));
             }
         } else {
 #pragma unroll AQUA_RESEED_UNROLL

@@ -602,6 +602,8 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const uint32_t q = qb + (lane / RESET_GROUP);
             const bool active = q < n_done;
             const uint32_t i = list[active ? q : 0];
+            // (rows through the scalar path here: with the quick-table form as a second inlined copy this kernel
+            // spills 125 SGPRs instead of 33 and the launch is 0.5 us slower; rollout_kernel takes it and gains)
             const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
                                                             tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1006,8 +1008,11 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepA
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
         const uint32_t owner = sh.list[parity][seg][active ? q - first[seg] : 0];
-        const EnvState f = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + block_first_world) + owner,
-                                                        tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
+        const EnvState f = (AQUA_QUICK_OTHERS != QUICK_NEVER && k.quick != nullptr)
+            ? reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                         k.K, k.obst, nullptr, k.quick, k.Kc)
+            : reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.result[q];
             r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
