@@ -20,9 +20,12 @@
 //               largest table read from LDS by the re-seeding pass; AQUA_NS_RESEED_PRIO (3); AQUA_RESEED_ROWS_PER_STEP,
 //               AQUA_RESEED_UNROLL, AQUA_TILE, AQUA_RESET_GROUP, AQUA_STORE_HINT / AQUA_LOAD_HINT (cache scopes),
 //               AQUA_OBST_LDS, AQUA_INLINE_RESEED, AQUA_INLINE_EXACT, AQUA_BAND_TIGHT, AQUA_PHILOX_ROUNDS
-//   ablations   AQUA_NO_PAIR_PHILOX, AQUA_NO_ARG_BATCH
+//   ablations   AQUA_NO_PAIR_PHILOX, AQUA_NO_ARG_BATCH, AQUA_NS_QUICK=0 / AQUA_QUICK_OTHERS=0 (obstacle look walks the
+//               rows instead of reading the quick table: next-step kernel / the other step kernels)
 //   experiments (results are NOT the product's): AQUA_NS_NOWORK (nobody restarts), AQUA_NS_NOMAIN (re-seeding
-//               blocks alone on a synthetic pending set), AQUA_EXP_NO_DEREF (table header and tick by value)
+//               blocks alone on a synthetic pending set), AQUA_EXP_NO_DEREF (table header and tick by value),
+//               AQUA_EXP_EXTRA_VALU=n (n extra vector instructions per stepping lane), AQUA_EXP_CLAMP_MINMAX,
+//               AQUA_EXP_NO_EXACT, AQUA_EXP_NO_SECOND, AQUA_EXP_ONE_ROUND
 //   diagnostics AQUA_STAMPS = 1 (phase stamps) | 2 (wavefront start/end only): tools/stamps*.py
 #include <hip/hip_runtime.h>
 

@@ -82,8 +82,10 @@ const char* aqua_last_error(void);
  * Obstacle table.  Replaces the per-object Python list of aqua.py:56-68.
  * rows: host float64 [K][5] = cx, cy, kind (0 circle | 1 rectangle), a (radius | width), b (0 | height).
  * aqua_pack_obstacles() writes the device-format blob (float32 clamp boxes + squared thresholds
- * for the fast path, then the float64 rows for the exact path) into HOST memory; the caller
- * uploads it and passes the device copy to the calls below.  K == 0 -> blob of 0 bytes, pass NULL.
+ * for the fast path, then the float64 rows for the exact path, then -- for K <= 8 -- the 384-byte
+ * "quick table": the fast path's operands once more as struct of arrays in groups of four obstacles)
+ * into HOST memory; the caller uploads it and passes the device copy to the calls below.
+ * Always size the buffer with aqua_obstacle_blob_bytes(K).  K == 0 -> blob of 0 bytes, pass NULL.
  */
 size_t aqua_obstacle_blob_bytes(int K);
 int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_bytes);
