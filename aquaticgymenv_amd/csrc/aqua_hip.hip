@@ -210,6 +210,9 @@ __device__ __forceinline__ ObstPtr stage_obstacles(ObstF*, const void* blob, int
 }
 #endif
 
+#ifndef AQUA_STEP_RESEED_QUICK              // step_kernel<.., SMALL>: re-seed from the quick table (1) or from the rows (0)
+#define AQUA_STEP_RESEED_QUICK 1
+#endif
 #ifndef AQUA_QUICK_OTHERS                   // the other step kernels: QUICK_IF_PRESENT (2) or QUICK_NEVER (0)
 #define AQUA_QUICK_OTHERS QUICK_IF_PRESENT
 #endif
@@ -501,10 +504,13 @@ __device__ __forceinline__ void fold_actions(const int64_t (&araw)[VEC], int (&a
     }
 }
 
-template <int VEC, int AK>
+// SMALL: the table has a quick table (at most QUICK_MAX rows; decided on the host like step_ns_kernel's
+// SMALL_TABLE): the obstacle look and the re-seeding read it, and nothing walks the rows outside the rare paths.
+template <int VEC, int AK, bool SMALL>
 __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
                                           TileShared& sh)
 {
+    constexpr int QUICK = (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_ALWAYS : QUICK_NEVER;
     constexpr int BLOCK = TILE_WORLDS / VEC;
     const int64_t ld = a.ld;
     const int64_t rem = a.N - tile;                      // > 0, uniform
@@ -560,7 +566,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         EnvState e{x[j], y[j], th[j], gx[j], gy[j], wx[j], wy[j], t[j]};
         mo[j] = decode_motion<AK>(k, aidx[j], avl[j], avr[j]);
         uint32_t c;
-        const bool knife = fast_step<false, AQUA_QUICK_OTHERS>(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
+        const bool knife = fast_step<false, QUICK>(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
         const bool valid = static_cast<int64_t>(off) + j < rem;
         knife_mask |= (knife && valid) ? (1u << j) : 0u;
         code[j] = static_cast<uint8_t>(c);
@@ -605,10 +611,13 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const uint32_t q = qb + (lane / RESET_GROUP);
             const bool active = q < n_done;
             const uint32_t i = list[active ? q : 0];
-            // (rows through the scalar path here: with the quick-table form as a second inlined copy this kernel
-            // spills 125 SGPRs instead of 33 and the launch is 0.5 us slower; rollout_kernel takes it and gains)
-            const EnvState e = reset_env_group<RESET_GROUP>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
-                                                            tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            const uint64_t world = static_cast<uint64_t>(a.env_offset + tile) + i;
+            EnvState e;
+            if constexpr (QUICK == QUICK_ALWAYS && AQUA_STEP_RESEED_QUICK)
+                e = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                               k.K, k.obst, nullptr, k.quick, k.Kc);
+            else
+                e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
                 st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
                 st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -657,16 +666,18 @@ __device__ __forceinline__ uint64_t launch_tick(const StepArgs& a)
     return a.tick + *(const uint64_t __attribute__((address_space(4)))*)(uintptr_t)a.tick_base;
 }
 
-template <int VEC, int AK>
+template <int VEC, int AK, bool SMALL>
 __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
     __shared__ TileShared sh;
     if (threadIdx.x == 0) sh.count = 0;
-    const StepConst k = make_const<AQUA_QUICK_OTHERS>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    // (the touches stay: the re-seeding may walk the rows, AQUA_STEP_RESEED_QUICK)
+    const StepConst k = make_const<(SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_IF_PRESENT : QUICK_NEVER>(
+        a, stage_obstacles(s_obst, a.obst_blob, a.K));
     if (a.auto_reset) __syncthreads();
     const uint64_t tick = launch_tick(a);
-    step_tile<VEC, AK>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
+    step_tile<VEC, AK, SMALL>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
 // ------------------------------------------------------------------ one launch per step, next-step restart
@@ -747,11 +758,15 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     // Small tables (the usual case) are copied into LDS by the first lanes -- one vector load each, in flight with
     // the time row -- and the obstacle pass of the re-seeding reads them from there after the barrier below,
     // four rows per wait (through the scalar path it waits once per two rows, 200 clocks each).
-    constexpr bool table_in_regs = SMALL_TABLE;
+#ifndef AQUA_NS_RESEED_QUICK                // 1: small tables are read from the quick table (SGPR operands) instead of LDS
+#define AQUA_NS_RESEED_QUICK 0
+#endif
+    constexpr bool reseed_quick = SMALL_TABLE && AQUA_NS_RESEED_QUICK;
+    constexpr bool table_in_regs = SMALL_TABLE && !reseed_quick;
     uint32_t table_word = 0;
     if (table_in_regs && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
         table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
-    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<reseed_quick ? QUICK_ALWAYS : QUICK_NEVER>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick = launch_tick(a);
     const int32_t restart = done_code(tick - 1);
     AQUA_RTSTAMP(0);
@@ -795,7 +810,10 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
         const uint64_t env = static_cast<uint64_t>(a.env_offset + base) + i;
         EnvState e;
-        if constexpr (SMALL_TABLE)
+        if constexpr (reseed_quick)
+            e = reset_env_group<NS_RESEED_GROUP, RESEED_QUICK>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst,
+                                                               nullptr, k.quick, k.Kc);
+        else if constexpr (SMALL_TABLE)
             e = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
         else
             e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
@@ -1362,16 +1380,23 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     const int64_t items = (a.N + VEC - 1) / VEC;
     if ((a.N + TILE_WORLDS - 1) / TILE_WORLDS > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(grid_for(items, TILE_WORLDS / VEC, MAX_GRID)), block(TILE_WORLDS / VEC);
+    const bool small = a.K > 0 && a.K <= QUICK_MAX;
+#define AQUA_STEP_LAUNCH(AK)                                                                         \
+    case AK:                                                                                         \
+        if (small) hipLaunchKernelGGL((step_kernel<VEC, AK, true>), grid, block, 0, s, a);           \
+        else hipLaunchKernelGGL((step_kernel<VEC, AK, false>), grid, block, 0, s, a);                \
+        break;
     switch (kind) {
-        case AQUA_ACT_U8: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_U8>), grid, block, 0, s, a); break;
-        case AQUA_ACT_I32: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_I32>), grid, block, 0, s, a); break;
-        case AQUA_ACT_I64: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_I64>), grid, block, 0, s, a); break;
-        case AQUA_ACT_F32X2: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
-        case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
-        case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
-        case AQUA_ACT_BEARING: hipLaunchKernelGGL((step_kernel<VEC, AQUA_ACT_BEARING>), grid, block, 0, s, a); break;
+        AQUA_STEP_LAUNCH(AQUA_ACT_U8)
+        AQUA_STEP_LAUNCH(AQUA_ACT_I32)
+        AQUA_STEP_LAUNCH(AQUA_ACT_I64)
+        AQUA_STEP_LAUNCH(AQUA_ACT_F32X2)
+        AQUA_STEP_LAUNCH(AQUA_ACT_SAMPLE_D)
+        AQUA_STEP_LAUNCH(AQUA_ACT_SAMPLE_C)
+        AQUA_STEP_LAUNCH(AQUA_ACT_BEARING)
         default: return hipErrorInvalidValue;
     }
+#undef AQUA_STEP_LAUNCH
     return hipGetLastError();
 }
 
