@@ -710,10 +710,8 @@ __device__ __forceinline__ bool reset_hit_world(int K, const WorldTable& t, cons
     return hit;
 }
 
-__device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env, uint64_t tick, int waves, int random_boat,
-                                                    int random_goal, int K, const WorldTable& t)
+__device__ __forceinline__ WorldRows load_world_rows(int K, const WorldTable& t)
 {
-#pragma clang fp contract(off)
     WorldRows rows;
     rows.cached = K <= WORLD_ROWS_IN_REGS;                 // uniform
 #pragma unroll
@@ -721,6 +719,14 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
         if (rows.cached && j < K) rows.r[j] = world_row(t, j);
         else { rows.r[j].cx = rows.r[j].cy = rows.r[j].hx = rows.r[j].hy = 0.0f; rows.r[j].r2 = -3.0e38f; rows.r[j].w = 1.0f; }
     }
+    return rows;
+}
+
+__device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env, uint64_t tick, int waves, int random_boat,
+                                                    int random_goal, int K, const WorldTable& t)
+{
+#pragma clang fp contract(off)
+    const WorldRows rows = load_world_rows(K, t);
     EnvState e;
     constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
     uint32_t r[4];
@@ -780,11 +786,16 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 #ifndef AQUA_RESEED_HALF_BARRIER
 #define AQUA_RESEED_HALF_BARRIER 1
 #endif
-constexpr int RESEED_QUICK = -1;
+// ROWS == RESEED_WORLD: the table is the group's OWN (per-world tables): `wt` names the world the group re-seeds; its
+// lanes read the same addresses, so a row costs the group one memory transaction per field.  Rows are read two at
+// a time inside the attempt loop (measured: all rows up front, 40 more live registers, made the masked reset
+// launch 10.2 us instead of 8.8; one world per lane with the rows cached: 10 us).
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2;
 template <int G, int ROWS = 0>
 __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
-                                                     const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0)
+                                                     const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
+                                                     const WorldTable* wt = nullptr)
 {
 #pragma clang fp contract(off)
     static_assert(G >= 2 && G <= 64 && (G & (G - 1)) == 0, "group size");
@@ -850,6 +861,12 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
                 hit_g = fg != 0u; hit_b = fb != 0u;
 #endif
             }
+        } else if constexpr (ROWS == RESEED_WORLD) {
+            for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
+                const ObstF r0 = world_row(*wt, j), r1 = world_row(*wt, j + 1 < K ? j + 1 : j);
+                test(r0.cx, r0.cy, r0.hx, r0.hy, r0.r2);
+                test(r1.cx, r1.cy, r1.hx, r1.hy, r1.r2);
+            }
         } else if constexpr (ROWS == RESEED_QUICK) {
             const auto circles = [&](const QuickCircles& g) {
 #pragma unroll
@@ -907,7 +924,13 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if (reset_hit(K, t, cx, cy)) continue;
+                if constexpr (ROWS == RESEED_WORLD) {
+                    WorldRows uncached;
+                    uncached.cached = false;
+                    if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;
+                } else {
+                    if (reset_hit(K, t, cx, cy)) continue;
+                }
                 bx = cx; by = cy; bt = heading;
                 break;
             }

@@ -1225,21 +1225,76 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
     }
 }
 
+// Masked reset against per-world tables.  A block reads the mask of RESET_SCAN worlds and compacts the selected ones
+// into an LDS list (ballot + prefix count per wavefront, one barrier).  Few selected (the restart after a step:
+// ~2 % of the worlds): they are re-seeded eight lanes per world like everywhere else -- with one world per lane,
+// three wavefronts of four would each loop over rejection attempts for one or two live lanes.  Many selected (a
+// whole-batch reset): one world per lane, the serial specification.  Bit-identical either way.
+constexpr int RESET_SCAN_ROWS = 4, RESET_SCAN = RESET_SCAN_ROWS * BLOCK_SMALL, RESET_DENSE = RESET_SCAN / 8;
+struct ResetShared {
+    uint32_t count[BLOCK_SMALL / 64];
+    uint16_t list[BLOCK_SMALL / 64][RESET_SCAN_ROWS * 64];
+};
 __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArgs a, const uint8_t* __restrict__ mask,
                                                                    const float* __restrict__ t32, int64_t tld)
 {
+    __shared__ ResetShared sh;
+    constexpr int WAVES = BLOCK_SMALL / 64;
     const uint64_t tick = launch_tick(a);
-    const int64_t N = a.N, ld = a.ld;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
-         i += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
-        if (mask != nullptr && mask[i] == 0) continue;
-        const WorldTable wt{t32, nullptr, tld, i};
-        const EnvState e = reset_env_world(a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat,
-                                           a.random_goal, a.K, wt);
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * RESET_SCAN, ld = a.ld, rem = a.N - base;   // rem > 0
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    bool sel[RESET_SCAN_ROWS];
+    uint32_t n_mine = 0;
+#pragma unroll
+    for (int j = 0; j < RESET_SCAN_ROWS; ++j) {
+        const uint32_t i = static_cast<uint32_t>(j * BLOCK_SMALL) + threadIdx.x;
+        sel[j] = static_cast<int64_t>(i) < rem && (mask == nullptr || mask[base + i] != 0);
+    }
+#pragma unroll
+    for (int j = 0; j < RESET_SCAN_ROWS; ++j) {
+        const uint32_t i = static_cast<uint32_t>(j * BLOCK_SMALL) + threadIdx.x;
+        const uint64_t m = __ballot(sel[j]);
+        if (sel[j]) sh.list[wave][n_mine + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = static_cast<uint16_t>(i);
+        n_mine += static_cast<uint32_t>(__builtin_popcountll(m));
+    }
+    if (lane == 0) sh.count[wave] = n_mine;
+    __syncthreads();
+    uint32_t first[WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.count[w];
+    const uint32_t n = uni(first[WAVES]);
+    const auto store = [&](int64_t i, const EnvState& e) {
         a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
         a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
         a.state[5 * ld + i] = e.wx; a.state[6 * ld + i] = e.wy;
         a.time[i] = e.t;
+    };
+    if (n > static_cast<uint32_t>(RESET_DENSE)) {
+#pragma unroll 1
+        for (int j = 0; j < RESET_SCAN_ROWS; ++j) {
+            if (!sel[j]) continue;
+            const int64_t i = base + j * BLOCK_SMALL + threadIdx.x;
+            const WorldTable wt{t32, nullptr, tld, i};
+            store(i, reset_env_world(a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat,
+                                     a.random_goal, a.K, wt));
+        }
+        return;
+    }
+    constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+    for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n; qb += PER_BLOCK) {
+        const uint32_t q = qb + (lane / RESET_GROUP);
+        const bool active = q < n;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+        const int64_t i = base + (active ? sh.list[seg][q - first[seg]] : 0);      // an idle group reads a world that exists
+        const WorldTable wt{t32, nullptr, tld, i};
+        const EnvState e = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
+                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
+                                                                      nullptr, 0, &wt);
+        if (active && (lane & (RESET_GROUP - 1)) == 0) store(i, e);
     }
 }
 
@@ -1862,7 +1917,8 @@ int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, in
     const int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
     if (rc) return rc;
     if (N == 0) return 0;
-    hipLaunchKernelGGL(reset_tables_kernel, dim3(grid_for(N, BLOCK_SMALL, 2048)), dim3(BLOCK_SMALL), 0,
+    if ((N + RESET_SCAN - 1) / RESET_SCAN > MAX_GRID) return fail(AQUA_E_INVALID, "N=%lld too large for one launch", (long long)N);
+    hipLaunchKernelGGL(reset_tables_kernel, dim3(static_cast<unsigned>((N + RESET_SCAN - 1) / RESET_SCAN)), dim3(BLOCK_SMALL), 0,
                        static_cast<hipStream_t>(stream), a, mask, tab32_dev, tld);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_reset_tables_f32 launch");

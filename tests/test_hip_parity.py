@@ -410,6 +410,31 @@ def test_per_world_tables_match_the_oracle(torch, oracle, continuous):
     assert finished > n // 20
 
 
+@pytest.mark.parametrize("density", [0.002, 0.03, 0.12, 0.13, 0.6, 1.0])
+def test_per_world_masked_reset_sparse_and_dense_masks_match_the_oracle(torch, oracle, density):
+    """the masked reset re-seeds few selected worlds eight lanes per world and many one world per lane (the switch is
+    per 1024-world block at 128 selected): both bit for bit the oracle's, and unselected worlds are untouched.
+    Crowded tables (9 rows with large obstacles) so that later attempt rounds are exercised."""
+    n, K = 20000 + 333, 9
+    rng = np.random.RandomState(int(density * 1000) + 5)
+    tables = _random_tables(rng, n, K)
+    tables[:, :, 3] *= 2.5                                     # radii / widths: more rejected placements
+    env = _make(torch, n, tables, seed=77, auto_reset=False, env_offset=4096)
+    env.reset()
+    torch.cuda.synchronize()
+    st, tt = _host_state(env)
+    mask = rng.uniform(size=n) < density
+    mask[1024:2048] = rng.uniform(size=1024) < 0.124          # one block just below the switch, one just above
+    mask[2048:3072] = rng.uniform(size=1024) < 0.127
+    env.reset(mask=torch.as_tensor(mask).cuda())
+    torch.cuda.synchronize()
+    k2, t2 = _host_state(env)
+    want_s, want_t = st.copy(), tt.copy()
+    oracle.reset_tables(want_s, want_t, tables, waves=1, seed=77, tick=env.RESET_TICK_BASE + 1, env_offset=4096, mask=mask)
+    assert np.array_equal(k2, want_s) and np.array_equal(t2, want_t)
+    assert np.array_equal(k2[:, ~mask], st[:, ~mask])
+
+
 # ------------------------------------------------------------------------------------------------
 # reset
 # ------------------------------------------------------------------------------------------------
