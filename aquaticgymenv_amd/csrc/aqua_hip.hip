@@ -1015,6 +1015,7 @@ __device__ __forceinline__ ReseedTicket publish_reseed(bool need, RolloutShared&
 }
 
 // the duty wavefront re-seeds the published worlds (tick: the tick whose draws the restart uses)
+template <bool SMALL>
 __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepArgs& a, const StepConst& k, uint64_t tick,
                                              int64_t block_first_world, RolloutShared& sh, int parity)
 {
@@ -1034,10 +1035,12 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepA
         for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
         const uint32_t owner = sh.list[parity][seg][active ? q - first[seg] : 0];
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
-        const EnvState f = (AQUA_QUICK_OTHERS != QUICK_NEVER && k.quick != nullptr)
-            ? reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
-                                                         k.K, k.obst, nullptr, k.quick, k.Kc)
-            : reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+        EnvState f;
+        if constexpr (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER)
+            f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                           k.K, k.obst, nullptr, k.quick, k.Kc);
+        else
+            f = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.result[q];
             r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
@@ -1055,12 +1058,15 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
     }
 }
 
-template <int AK>
+// SMALL: the table has a quick table (host-selected, as for step_kernel): one inlined copy of the obstacle look and of
+// the re-seeding instead of two behind run-time branches
+template <int AK, bool SMALL>
 __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
     __shared__ RolloutShared sh;
-    const StepConst k = make_const<AQUA_QUICK_OTHERS>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    constexpr int QUICK = (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_ALWAYS : QUICK_NEVER;
+    const StepConst k = make_const<QUICK == QUICK_ALWAYS ? QUICK_IF_PRESENT : QUICK_NEVER>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     // whole blocks iterate together (barriers inside); lanes past N are inert
@@ -1084,7 +1090,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
                 restart = valid && e.t == done_code(tick - 1);
                 pending = valid && e.t < 0;
                 tk = publish_reseed(restart, sh, parity);
-                serve_reseed(tk, a, k, tick, bbase, sh, parity);     // one wavefront; the others go on stepping
+                serve_reseed<SMALL>(tk, a, k, tick, bbase, sh, parity);     // one wavefront; the others go on stepping
             }
             int idx = 2;
             float vl = 0.5f, vr = 0.5f;
@@ -1109,7 +1115,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
             EnvState after = e;
             float rew;
             uint32_t code;
-            const bool knife = fast_step<false, AQUA_QUICK_OTHERS>(after, m.h, m.w, m.chord, u0, u1, k, rew, code) && valid && !pending;
+            const bool knife = fast_step<false, QUICK>(after, m.h, m.w, m.chord, u0, u1, k, rew, code) && valid && !pending;
             if (any_lane(knife)) {
                 if (knife) {
                     const ExactOut o = exact_step(before.x, before.y, before.th, before.gx, before.gy, before.wx,
@@ -1131,7 +1137,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
                 else if (done) e.t = done_code(tick);
             } else if (a.auto_reset == AQUA_RESET_SAME_STEP) {
                 const ReseedTicket t1 = publish_reseed(done, sh, parity);
-                serve_reseed(t1, a, k, tick, bbase, sh, parity);
+                serve_reseed<SMALL>(t1, a, k, tick, bbase, sh, parity);
                 collect_reseed(e, done, t1, sh);
             }
         }
@@ -1803,14 +1809,21 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;
     const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool small = K > 0 && K <= QUICK_MAX;
+#define AQUA_ROLLOUT_LAUNCH(AK)                                                                      \
+    case AK:                                                                                         \
+        if (small) hipLaunchKernelGGL((rollout_kernel<AK, true>), grid, block, 0, s, a);             \
+        else hipLaunchKernelGGL((rollout_kernel<AK, false>), grid, block, 0, s, a);                  \
+        break;
     switch (action_kind) {
-        case AQUA_ACT_U8: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_U8>), grid, block, 0, s, a); break;
-        case AQUA_ACT_I32: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_I32>), grid, block, 0, s, a); break;
-        case AQUA_ACT_I64: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_I64>), grid, block, 0, s, a); break;
-        case AQUA_ACT_F32X2: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_F32X2>), grid, block, 0, s, a); break;
-        case AQUA_ACT_SAMPLE_D: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_SAMPLE_D>), grid, block, 0, s, a); break;
-        case AQUA_ACT_SAMPLE_C: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_SAMPLE_C>), grid, block, 0, s, a); break;
-        case AQUA_ACT_BEARING: hipLaunchKernelGGL((rollout_kernel<AQUA_ACT_BEARING>), grid, block, 0, s, a); break;
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_U8)
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_I32)
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_I64)
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_F32X2)
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_SAMPLE_D)
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_SAMPLE_C)
+        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_BEARING)
+#undef AQUA_ROLLOUT_LAUNCH
         default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
     }
     const hipError_t e = hipGetLastError();
