@@ -1060,8 +1060,9 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 
 // SMALL: the table has a quick table (host-selected, as for step_kernel): one inlined copy of the obstacle look and of
 // the re-seeding instead of two behind run-time branches
-template <int AK, bool SMALL>
-__global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
+// MODE: a.auto_reset, likewise host-selected: one inlined copy of the re-seeding (or none) in the loop
+template <int AK, bool SMALL, int MODE>
+__global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs a)     // 4 wavefronts per SIMD: <= 128 VGPRs
 {
     AQUA_OBST_DECL
     __shared__ RolloutShared sh;
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
             // move this tick, it is re-seeded instead; any other marker waits
             bool pending = false, restart = false;
             ReseedTicket tk{0u, 0u};
-            if (a.auto_reset == AQUA_RESET_NEXT_STEP) {
+            if constexpr (MODE == AQUA_RESET_NEXT_STEP) {
                 if (e.t == restart_code(tick - 1)) e.t = 0;
                 restart = valid && e.t == done_code(tick - 1);
                 pending = valid && e.t < 0;
@@ -1131,11 +1132,11 @@ __global__ __launch_bounds__(BLOCK_SMALL) void rollout_kernel(const StepArgs a)
                 a.term[s * a.out_step_stride + i] = static_cast<uint8_t>(code);
             }
             const bool done = valid && code != 0u;
-            if (a.auto_reset == AQUA_RESET_NEXT_STEP) {
+            if constexpr (MODE == AQUA_RESET_NEXT_STEP) {
                 collect_reseed(e, restart, tk, sh);
                 if (restart) e.t = restart_code(tick);
                 else if (done) e.t = done_code(tick);
-            } else if (a.auto_reset == AQUA_RESET_SAME_STEP) {
+            } else if constexpr (MODE == AQUA_RESET_SAME_STEP) {
                 const ReseedTicket t1 = publish_reseed(done, sh, parity);
                 serve_reseed<SMALL>(t1, a, k, tick, bbase, sh, parity);
                 collect_reseed(e, done, t1, sh);
@@ -1810,10 +1811,16 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool small = K > 0 && K <= QUICK_MAX;
+#define AQUA_ROLLOUT_MODE(AK, SM)                                                                                         \
+    do {                                                                                                                  \
+        if (auto_reset == AQUA_RESET_NEXT_STEP) hipLaunchKernelGGL((rollout_kernel<AK, SM, AQUA_RESET_NEXT_STEP>), grid, block, 0, s, a); \
+        else if (auto_reset == AQUA_RESET_SAME_STEP) hipLaunchKernelGGL((rollout_kernel<AK, SM, AQUA_RESET_SAME_STEP>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((rollout_kernel<AK, SM, 0>), grid, block, 0, s, a);                                       \
+    } while (0)
 #define AQUA_ROLLOUT_LAUNCH(AK)                                                                      \
     case AK:                                                                                         \
-        if (small) hipLaunchKernelGGL((rollout_kernel<AK, true>), grid, block, 0, s, a);             \
-        else hipLaunchKernelGGL((rollout_kernel<AK, false>), grid, block, 0, s, a);                  \
+        if (small) AQUA_ROLLOUT_MODE(AK, true);                                                      \
+        else AQUA_ROLLOUT_MODE(AK, false);                                                           \
         break;
     switch (action_kind) {
         AQUA_ROLLOUT_LAUNCH(AQUA_ACT_U8)
@@ -1824,6 +1831,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
         AQUA_ROLLOUT_LAUNCH(AQUA_ACT_SAMPLE_C)
         AQUA_ROLLOUT_LAUNCH(AQUA_ACT_BEARING)
 #undef AQUA_ROLLOUT_LAUNCH
+#undef AQUA_ROLLOUT_MODE
         default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
     }
     const hipError_t e = hipGetLastError();
