@@ -238,49 +238,105 @@ def test_step_matches_oracle_philox(torch, oracle, vec, n, continuous, obst):
         _compare_with_oracle(torch, oracle, env, state0, time0, a_or, reward.cpu().numpy(), term.cpu().numpy(), tick)
 
 
+def _rollout_against_oracle(torch, oracle, rows, n, steps, continuous, mode, env_offset, seed=99):
+    """device-sampled actions + restart of finished worlds against the oracle's float32-state rollout, teacher-forced
+    per step (the oracle restarts from the kernel's state every step).  Returns the number of finished episodes."""
+    env = _make(torch, n, rows, continuous=continuous, seed=seed, auto_reset=mode, env_offset=env_offset)
+    env.reset()
+    finished = 0
+    for it in range(steps):
+        s0, t0 = _host_state(env)
+        tick = env._tick
+        obs, reward, term = env.step(sample_actions=True)
+        torch.cuda.synchronize()
+        st = np.ascontiguousarray(s0.copy())
+        tt = t0.copy()
+        ep, o_rew, o_term, counts = oracle.rollout_f32(st, tt, 1, obstacles=env.obstacle_rows, waves=1,
+                                                        continuous=continuous, seed=env.seed, tick0=tick,
+                                                        env_offset=env_offset, auto_reset=mode)
+        k_state, k_time = _host_state(env)
+        term_h, rew_h = term.cpu().numpy(), reward.cpu().numpy()
+        assert np.array_equal(term_h, o_term)
+        assert np.max(np.abs(rew_h - o_rew)) <= TOL
+        assert np.array_equal(k_time, tt)
+        assert np.array_equal(env.done_mask().cpu().numpy(), (o_term != 0).astype(np.uint8))
+        reseeded = (o_term != 0) if mode == 1 else (t0 == -1 - ((tick - 1) & 1))
+        # worlds that restarted: float32 reset specification, bit for bit
+        assert np.array_equal(k_state[:, reseeded], st[:, reseeded])
+        if mode == 2:
+            assert np.all(rew_h[reseeded] == 0) and np.all(term_h[reseeded] == 0)
+            assert np.all(k_time[reseeded] == -3 - (tick & 1))        # restarted this tick, steps from 0 next tick
+            assert np.all(k_time[o_term != 0] == -1 - (tick & 1))     # marker carries the finishing tick's parity
+        live = ~reseeded
+        assert np.max(np.abs(k_state[0:2, live] - st[0:2, live])) <= TOL
+        assert np.max(angle_diff(k_state[2, live], st[2, live])) <= TOL
+        assert np.max(np.abs(k_state[5:7, live] - st[5:7, live])) <= 1e-7
+        assert np.array_equal(k_state[3:5, live], st[3:5, live])
+        finished += int((o_term != 0).sum())
+    return finished
+
+
 @pytest.mark.parametrize("mode,env_offset", [(1, 0), (2, 0), (2, 7)], ids=["same_step", "next_step", "next_step_odd_offset"])
 def test_sampled_actions_match_oracle_rollout(torch, oracle, mode, env_offset):
-    """device-sampled actions + restart of finished worlds, 40 steps, against the oracle's float32-state
-    rollout: teacher-forced per step (the oracle restarts from the kernel's state every step).
-    mode 1: finished worlds are re-seeded in the launch that finished them; mode 2 (next-step): they are
-    marked pending (time == -1 - (tick & 1)) and re-seeded during the next step, which reports reward 0 / term 0."""
+    """40 steps, discrete and continuous.  mode 1: finished worlds are re-seeded in the launch that finished them;
+    mode 2 (next-step): they are marked pending (time == -1 - (tick & 1)) and re-seeded during the next step, which
+    reports reward 0 / term 0.  (An odd env_offset puts the two worlds of a Philox pair on lanes 2i + 1, 2i + 2:
+    the per-lane fallback.)"""
     from aquaticgymenv_amd import presets
     n = 8192 + 37
     for continuous in (False, True):
-        # (an odd env_offset puts the two worlds of a Philox pair on lanes 2i + 1, 2i + 2: the per-lane fallback)
-        env = _make(torch, n, presets.BENCH8, continuous=continuous, seed=99, auto_reset=mode, env_offset=env_offset)
+        finished = _rollout_against_oracle(torch, oracle, presets.BENCH8, n, 40, continuous, mode, env_offset)
+        assert finished > n // 4
+
+
+def _obstacle_mix(n_circles, n_rects, seed):
+    """reference-format rows [K][5] in the given order of kinds (circles and rectangles interleaved at random)"""
+    rng = np.random.RandomState(seed)
+    kinds = np.array([0.0] * n_circles + [1.0] * n_rects)
+    rng.shuffle(kinds)
+    rows = np.zeros((len(kinds), 5))
+    rows[:, 0:2] = rng.uniform(12, 88, (len(kinds), 2))
+    rows[:, 2] = kinds
+    rows[:, 3] = np.where(kinds == 0, rng.uniform(2, 6, len(kinds)), rng.uniform(4, 12, len(kinds)))
+    rows[:, 4] = np.where(kinds == 0, 0.0, rng.uniform(4, 12, len(kinds)))
+    return rows
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["no_restart", "same_step", "next_step"])
+@pytest.mark.parametrize("mix", [(1, 0), (0, 1), (3, 2), (5, 0), (0, 5), (8, 0), (0, 8), (7, 1), (1, 6), (4, 4), (9, 3), (2, 14)],
+                         ids=lambda m: "c%dr%d" % m)
+def test_obstacle_table_shapes_match_oracle_rollout(torch, oracle, mix, mode):
+    """every shape of the quick table (first groups only, second circle group, second rectangle group, both, none of
+    a kind) and tables too long to have one (K > 8: the row loops), in every restart mode, per-step kernels against
+    the oracle and the fused rollout against the per-step kernels."""
+    rows = _obstacle_mix(mix[0], mix[1], seed=mix[0] * 17 + mix[1])
+    n = 3000 + 11
+    if mode == 0:
+        env = _make(torch, n, rows, seed=5, auto_reset=False)
         env.reset()
-        finished = 0
-        for it in range(40):
+        rng = np.random.RandomState(3)
+        for it in range(25):
             s0, t0 = _host_state(env)
             tick = env._tick
-            obs, reward, term = env.step(sample_actions=True)
+            act = rng.randint(0, 3, n).astype(np.uint8)
+            obs, reward, term = env.step(torch.as_tensor(act).cuda())
             torch.cuda.synchronize()
-            st = np.ascontiguousarray(s0.copy())
-            tt = t0.copy()
-            ep, o_rew, o_term, counts = oracle.rollout_f32(st, tt, 1, obstacles=env.obstacle_rows, waves=1,
-                                                            continuous=continuous, seed=env.seed, tick0=tick,
-                                                            env_offset=env_offset, auto_reset=mode)
+            s64 = np.ascontiguousarray(s0.astype(np.float64))
+            t = np.ascontiguousarray(t0.astype(np.int32))
+            o_rew, o_term, margins = oracle.step(s64, t, act, obstacles=rows, waves=1, seed=5, tick=tick)
             k_state, k_time = _host_state(env)
-            term_h, rew_h = term.cpu().numpy(), reward.cpu().numpy()
-            assert np.array_equal(term_h, o_term)
-            assert np.max(np.abs(rew_h - o_rew)) <= TOL
-            assert np.array_equal(k_time, tt)
-            assert np.array_equal(env.done_mask().cpu().numpy(), (o_term != 0).astype(np.uint8))
-            reseeded = (o_term != 0) if mode == 1 else (t0 == -1 - ((tick - 1) & 1))
-            # worlds that restarted: float32 reset specification, bit for bit
-            assert np.array_equal(k_state[:, reseeded], st[:, reseeded])
-            if mode == 2:
-                assert np.all(rew_h[reseeded] == 0) and np.all(term_h[reseeded] == 0)
-                assert np.all(k_time[reseeded] == -3 - (tick & 1))        # restarted this tick, steps from 0 next tick
-                assert np.all(k_time[o_term != 0] == -1 - (tick & 1))     # marker carries the finishing tick's parity
-            live = ~reseeded
-            assert np.max(np.abs(k_state[0:2, live] - st[0:2, live])) <= TOL
-            assert np.max(angle_diff(k_state[2, live], st[2, live])) <= TOL
-            assert np.max(np.abs(k_state[5:7, live] - st[5:7, live])) <= 1e-7
-            assert np.array_equal(k_state[3:5, live], st[3:5, live])
-            finished += int((o_term != 0).sum())
-        assert finished > n // 4
+            assert np.array_equal(term.cpu().numpy(), o_term)
+            assert np.max(np.abs(k_state[0:2] - s64[0:2])) <= TOL and np.max(np.abs(reward.cpu().numpy() - o_rew)) <= TOL
+        return
+    finished = _rollout_against_oracle(torch, oracle, rows, n, 25, False, mode, 0, seed=5)
+    assert finished > 0
+    a = _make(torch, n, rows, seed=6, auto_reset=mode)
+    b = _make(torch, n, rows, seed=6, auto_reset=mode)
+    a.reset(); b.reset()
+    ra, ta = a.rollout(30, fused=False, keep_all=True)
+    rb, tb = b.rollout(30, fused=True, keep_all=True)
+    assert torch.equal(ra[:, :n], rb[:, :n]) and torch.equal(ta[:, :n], tb[:, :n])          # (columns n.. are padding)
+    assert torch.equal(a.state[:, :n], b.state[:, :n]) and torch.equal(a.time[:n], b.time[:n])
 
 
 def test_masked_reset_between_steps_does_not_delay_restarts(torch):
