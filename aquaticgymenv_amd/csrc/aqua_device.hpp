@@ -136,7 +136,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 #ifndef AQUA_PHILOX_ROUNDS
 #define AQUA_PHILOX_ROUNDS 10
 #endif
-#pragma unroll
+#ifndef AQUA_PHILOX_UNROLL                  // round bodies per loop iteration of the per-lane form (10: fully unrolled)
+#define AQUA_PHILOX_UNROLL 10
+#endif
+#pragma unroll AQUA_PHILOX_UNROLL
     for (int r = 0; r < AQUA_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 product per half round (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32:
         // integer multiplies issue at a quarter of the VALU rate and are the bulk of this routine

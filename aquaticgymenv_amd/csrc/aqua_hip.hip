@@ -19,7 +19,8 @@
 //               scanned per re-seeding block; AQUA_NS_RESEED_GROUP (8) lanes per restarting world; AQUA_NS_TABLE_ROWS (8)
 //               largest table read from LDS by the re-seeding pass; AQUA_NS_RESEED_PRIO (3); AQUA_RESEED_ROWS_PER_STEP,
 //               AQUA_RESEED_UNROLL, AQUA_TILE, AQUA_RESET_GROUP, AQUA_STORE_HINT / AQUA_LOAD_HINT (cache scopes),
-//               AQUA_OBST_LDS, AQUA_INLINE_RESEED, AQUA_INLINE_EXACT, AQUA_BAND_TIGHT, AQUA_PHILOX_ROUNDS
+//               AQUA_OBST_LDS, AQUA_INLINE_RESEED, AQUA_INLINE_EXACT, AQUA_BAND_TIGHT, AQUA_PHILOX_ROUNDS, AQUA_PHILOX_UNROLL,
+//               AQUA_STEP_RESEED_QUICK, AQUA_NS_RESEED_QUICK
 //   ablations   AQUA_NO_PAIR_PHILOX, AQUA_NO_ARG_BATCH, AQUA_NS_QUICK=0 / AQUA_QUICK_OTHERS=0 (obstacle look walks the
 //               rows instead of reading the quick table: next-step kernel / the other step kernels)
 //   experiments (results are NOT the product's): AQUA_NS_NOWORK (nobody restarts), AQUA_NS_NOMAIN (re-seeding
