@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 1
+#define AQUA_ABI_VERSION 2   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
