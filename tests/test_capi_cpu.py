@@ -82,6 +82,38 @@ def test_pack_obstacles_layout(capi):
         capi.pack_obstacles(np.zeros((65, 5)))
 
 
+def test_quick_table_mirrors_the_rows_for_every_mix(capi):
+    """K = 1..8 with every number of circles: each circle / rectangle slot of the quick table holds its row's values
+    (circles first, original order within a kind), -r2 for r2, and unused slots hold (0, 0, [0, 0,] 1e30)."""
+    rng = np.random.RandomState(4)
+    for k in range(1, 9):
+        for n_circles in range(0, k + 1):
+            kinds = np.array([0.0] * n_circles + [1.0] * (k - n_circles))
+            rng.shuffle(kinds)
+            rows = np.zeros((k, 5))
+            rows[:, 0:2] = rng.uniform(10, 90, (k, 2))
+            rows[:, 2] = kinds
+            rows[:, 3] = rng.uniform(2, 9, k)
+            rows[:, 4] = np.where(kinds == 0, 0.0, rng.uniform(2, 9, k))
+            blob = capi.pack_obstacles(rows)
+            quick = (32 + k * 72 + 63) // 64 * 64
+            assert len(blob) == quick + 384 and np.frombuffer(blob[20:24], dtype=np.int32)[0] == quick
+            packed = np.frombuffer(blob[32:32 + k * 32], dtype=np.float32).reshape(k, 8)      # cx cy hx hy r2 w . .
+            q = np.frombuffer(blob[quick:], dtype=np.float32).reshape(24, 4)
+            circles = np.concatenate([q[0:3], q[4:7]], axis=1)                                  # [cx cy -r2][8 slots]
+            rects = np.concatenate([q[8:13], q[16:21]], axis=1)                                 # [cx cy hx hy -r2][8]
+            for j in range(8):
+                if j < n_circles:
+                    assert np.array_equal(circles[:, j], packed[j, [0, 1, 4]] * np.float32([1, 1, -1]))
+                else:
+                    assert np.array_equal(circles[:, j], np.float32([0, 0, 1e30]))
+                if j < k - n_circles:
+                    assert np.array_equal(rects[:, j], packed[n_circles + j, [0, 1, 2, 3, 4]] * np.float32([1, 1, 1, 1, -1]))
+                else:
+                    assert np.array_equal(rects[:, j], np.float32([0, 0, 0, 0, 1e30]))
+            assert np.all(packed[:n_circles, 2:4] == 0) and np.all(packed[n_circles:, 2:4] > 0)
+
+
 def test_pack_tables_layout(capi):
     """per-world tables: struct of arrays over the worlds, absent rows never hit, per-row band scale, r_max."""
     lib = capi.lib
