@@ -511,7 +511,9 @@ __device__ __forceinline__ void fold_actions(const int64_t (&araw)[VEC], int (&a
 
 // SMALL: the table has a quick table (at most QUICK_MAX rows; decided on the host like step_ns_kernel's
 // SMALL_TABLE): the obstacle look and the re-seeding read it, and nothing walks the rows outside the rare paths.
-template <int VEC, int AK, bool SMALL>
+// RESTART == false: the launch never restarts a world (auto_reset 0, the reference's own step()): no list, no
+// barrier, no re-seeding code in the kernel.  RESTART == true serves both (the run-time a.auto_reset decides).
+template <int VEC, int AK, bool SMALL, bool RESTART>
 __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
                                           TileShared& sh)
 {
@@ -598,7 +600,7 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
     uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
     constexpr uint32_t own_reset_mask = 0;
-    if (a.auto_reset) {
+    if (RESTART && a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
 #pragma unroll
@@ -671,18 +673,18 @@ __device__ __forceinline__ uint64_t launch_tick(const StepArgs& a)
     return a.tick + *(const uint64_t __attribute__((address_space(4)))*)(uintptr_t)a.tick_base;
 }
 
-template <int VEC, int AK, bool SMALL>
+template <int VEC, int AK, bool SMALL, bool RESTART>
 __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
     __shared__ TileShared sh;
-    if (threadIdx.x == 0) sh.count = 0;
+    if (RESTART && threadIdx.x == 0) sh.count = 0;
     // (the touches stay: the re-seeding may walk the rows, AQUA_STEP_RESEED_QUICK)
     const StepConst k = make_const<(SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_IF_PRESENT : QUICK_NEVER>(
         a, stage_obstacles(s_obst, a.obst_blob, a.K));
-    if (a.auto_reset) __syncthreads();
+    if (RESTART && a.auto_reset) __syncthreads();
     const uint64_t tick = launch_tick(a);
-    step_tile<VEC, AK, SMALL>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
+    step_tile<VEC, AK, SMALL, RESTART>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
 // ------------------------------------------------------------------ one launch per step, next-step restart
@@ -1448,10 +1450,14 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     if ((a.N + TILE_WORLDS - 1) / TILE_WORLDS > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(grid_for(items, TILE_WORLDS / VEC, MAX_GRID)), block(TILE_WORLDS / VEC);
     const bool small = a.K > 0 && a.K <= QUICK_MAX;
-#define AQUA_STEP_LAUNCH(AK)                                                                         \
-    case AK:                                                                                         \
-        if (small) hipLaunchKernelGGL((step_kernel<VEC, AK, true>), grid, block, 0, s, a);           \
-        else hipLaunchKernelGGL((step_kernel<VEC, AK, false>), grid, block, 0, s, a);                \
+    // (the no-restart specialisation exists for one world per lane, the width every batch size runs fastest at)
+    const bool plain = VEC == 1 && a.auto_reset == 0;
+#define AQUA_STEP_LAUNCH(AK)                                                                                     \
+    case AK:                                                                                                     \
+        if (plain && small) hipLaunchKernelGGL((step_kernel<VEC, AK, true, VEC != 1>), grid, block, 0, s, a);    \
+        else if (plain) hipLaunchKernelGGL((step_kernel<VEC, AK, false, VEC != 1>), grid, block, 0, s, a);       \
+        else if (small) hipLaunchKernelGGL((step_kernel<VEC, AK, true, true>), grid, block, 0, s, a);            \
+        else hipLaunchKernelGGL((step_kernel<VEC, AK, false, true>), grid, block, 0, s, a);                      \
         break;
     switch (kind) {
         AQUA_STEP_LAUNCH(AQUA_ACT_U8)
