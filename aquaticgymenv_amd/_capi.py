@@ -61,7 +61,7 @@ def _load():
     lib.aqua_ring_write_u8.argtypes = [vp, i64, i64, i64, vp, i64, ci, i64, vp]
     lib.aqua_pack_tables.argtypes = [vp, ci, i64, i64, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.aqua_step_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, vp, ci, i64, vp, i64,
-                                         u64, u64, vp, vp, vp, vp, vp, vp]
+                                         u64, u64, vp, vp, vp, vp, vp, ci, vp]
     lib.aqua_reset_tables_f32.argtypes = [pp, vp, ci, i64, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_graph_begin.argtypes = [vp]
     lib.aqua_graph_end.argtypes = [vp, ctypes.POINTER(vp)]

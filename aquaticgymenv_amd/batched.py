@@ -110,8 +110,8 @@ class BatchedAqua(object):
             self._r_max = 0.0
             if self.per_world:
                 if self.auto_reset == 2:
-                    raise ValueError("per-world obstacle tables: auto_reset is False or 'same_step' (a masked reset launch "
-                                     "behind every step); 'next_step' is the shared-table kernel's")
+                    raise ValueError("per-world obstacle tables: auto_reset is False or 'same_step'; 'next_step' is the "
+                                     "shared-table kernel's")
                 t32 = np.zeros((self.K, 6, self.ld), dtype=np.float32)
                 t64 = np.zeros((self.K, 5, self.ld), dtype=np.float64)
                 r_max = ctypes.c_float(0.0)
@@ -272,18 +272,9 @@ class BatchedAqua(object):
                                                            self.env_offset, self.state.data_ptr(), self.ld,
                                                            self.time.data_ptr(), aptr, kind, ald, nptr, nld, self.seed,
                                                            self._tick, None, self.reward.data_ptr(), self.term.data_ptr(),
-                                                           self.done_bits.data_ptr(), self._norm_ptr(), self._stream()),
-                            "aqua_step_tables_f32")
-                if self.auto_reset == 1:      # restart what just finished: exactly reset(mask=term), one more launch
-                    _capi.check(_capi.lib.aqua_reset_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self.K,
-                                                                self.ld, n, self.env_offset, self.state.data_ptr(), self.ld,
-                                                                self.time.data_ptr(), self.term.data_ptr(), self.seed,
-                                                                self.RESET_TICK_BASE + self._resets, None, self._stream()),
-                                "aqua_reset_tables_f32")
-                    if self._norm_ptr() is not None:
-                        _capi.check(_capi.lib.aqua_obs_norm_f32(self.state.data_ptr(), self.ld, n, self.term.data_ptr(),
-                                                                self._norm_ptr(), self._stream()), "aqua_obs_norm_f32")
-                    self._resets += 1
+                                                           self.done_bits.data_ptr(), self._norm_ptr(), int(self.auto_reset),
+                                                           self._stream()),
+                            "aqua_step_tables_f32")           # (same-step restart happens inside the launch)
             else:
                 _capi.check(_capi.lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
                                                     self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald,
@@ -404,8 +395,8 @@ class BatchedAqua(object):
         return g
 
     def capture_steps_per_world(self, steps, actions):
-        """Per-world obstacle tables: capture `steps` x (one step launch + one masked reset of the worlds that just
-        finished, mask = the step's termination codes) into a HIP graph.  actions: uint8 [steps][ld] (discrete).
+        """Per-world obstacle tables: capture `steps` step launches (restart per self.auto_reset: none, or same-step
+        inside the launch) into a HIP graph.  actions: uint8 [steps][ld] (discrete).
         Ticks come from the device-resident base like capture_rollout()'s, so replays draw fresh noise."""
         if not self.per_world or self.continuous:
             raise NotImplementedError("capture_steps_per_world: discrete worlds with per-world obstacle tables")
@@ -430,14 +421,7 @@ class BatchedAqua(object):
                                                   self.state.data_ptr(), self.ld, self.time.data_ptr(),
                                                   actions[i].data_ptr(), _capi.ACT_U8, 0, None, 0, self.seed, i, tb,
                                                   self.reward.data_ptr(), self.term.data_ptr(), self.done_bits.data_ptr(),
-                                                  self._norm_ptr(), s)
-                    if rc:
-                        break
-                    # restart what just finished: its draws use the restart range of this tick (tick base + i)
-                    rc = lib.aqua_reset_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self.K, self.ld,
-                                                   self.num_envs, self.env_offset, self.state.data_ptr(), self.ld,
-                                                   self.time.data_ptr(), self.term.data_ptr(), self.seed,
-                                                   self.RESET_TICK_BASE // 2 + i, tb, s)
+                                                  self._norm_ptr(), int(self.auto_reset), s)
                     if rc:
                         break
                 if rc == 0:

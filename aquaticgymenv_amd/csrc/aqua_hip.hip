@@ -1158,7 +1158,14 @@ __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs 
 // One launch per batched step, no restart (the caller resets with reset_tables_kernel): one world per lane, every
 // lane reads the rows of its own table (WorldTable, struct of arrays over the worlds: coalesced), generic box
 // formula for every row.  The arithmetic, the bands and the float64 path are the shared-table kernels'.
-template <int AK>
+// RESTART (auto_reset 1, same-step): worlds that finish are published on an LDS list (one private segment per
+// wavefront) and, after ONE barrier, re-seeded eight lanes per world against their own tables (draws of this tick,
+// like step_kernel); the owning lane keeps its reward / term stores and skips its state stores.
+struct TablesShared {
+    uint32_t count[BLOCK_SMALL / 64];
+    uint8_t list[BLOCK_SMALL / 64][64];
+};
+template <int AK, bool RESTART>
 __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
@@ -1227,15 +1234,51 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
     if (valid) {
         st_at(a.reward + tile, o4, rew);
         st_at(a.term + tile, o, static_cast<uint8_t>(code));
-        st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
-        st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
-        st_at(trow, o4, e.t);
-        write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
+        if (!(RESTART && done)) {                         // a finished world's fresh state is written by its group below
+            st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
+            st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
+            st_at(trow, o4, e.t);
+            write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
+        }
     }
+    const uint64_t done_ballot = __ballot(done);
     if (a.done_bits != nullptr) {
-        const uint64_t b = __ballot(done);
         const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
-        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = done_ballot;
+    }
+    if constexpr (RESTART) {
+        __shared__ TablesShared sh;
+        constexpr int WAVES = BLOCK_SMALL / 64;
+        const int wave = threadIdx.x >> 6;
+        if (done) sh.list[wave][__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done_ballot >> 32),
+                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(done_ballot), 0u))] = static_cast<uint8_t>(threadIdx.x);
+        if (lane == 0) sh.count[wave] = static_cast<uint32_t>(__builtin_popcountll(done_ballot));
+        __syncthreads();
+        uint32_t first[WAVES + 1];
+        first[0] = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.count[w];
+        const uint32_t n_done = uni(first[WAVES]);
+        constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+        for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_done; qb += PER_BLOCK) {
+            const uint32_t q = qb + (lane / RESET_GROUP);
+            const bool active = q < n_done;
+            uint32_t seg = 0;
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+            const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
+            const WorldTable own{t32, nullptr, tld, tile + i};
+            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
+                                                                          tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
+                                                                          nullptr, nullptr, 0, &own);
+            if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
+                st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
+                st1(row0 + 5 * ld + i, f.wx); st1(row0 + 6 * ld + i, f.wy);
+                st1(trow + i, f.t);
+                write_norm(a, tile + i, f.x, f.y, f.th, f.gx, f.gy);
+            }
+        }
     }
 }
 
@@ -1905,9 +1948,11 @@ int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const doub
                          float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time,
                          const void* action, int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld,
                          uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
-                         uint64_t* done_bits, float* obs_norm, void* stream)
+                         uint64_t* done_bits, float* obs_norm, int auto_reset, void* stream)
 {
     StepArgs a;
+    if (auto_reset != AQUA_RESET_NONE && auto_reset != AQUA_RESET_SAME_STEP)
+        return fail(AQUA_E_INVALID, "per-world tables: auto_reset must be 0 (none) or 1 (same step), got %d", auto_reset);
     int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
     if (rc) return rc;
     if (tab64_dev == nullptr || !aligned(tab64_dev, 8)) return fail(AQUA_E_INVALID, "tab64 is NULL or not 8-byte aligned");
@@ -1916,7 +1961,7 @@ int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const doub
     if (rc) return rc;
     if (N == 0) return 0;
     a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
-    a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = AQUA_RESET_NONE;
+    a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = auto_reset;
     const double R = static_cast<double>(r_max);
     const float band2 = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND));
     const float band2_tight = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) +
@@ -1925,7 +1970,11 @@ int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const doub
     if (blocks > MAX_GRID) return fail(AQUA_E_INVALID, "N too large for one launch");
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define AQUA_TAB_LAUNCH(AK) case AK: hipLaunchKernelGGL((step_tables_kernel<AK>), grid, block, 0, s, a, tab32_dev, tab64_dev, tld, band2, band2_tight); break;
+#define AQUA_TAB_LAUNCH(AK)                                                                                                          \
+    case AK:                                                                                                                          \
+        if (auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, true>), grid, block, 0, s, a, tab32_dev, tab64_dev, tld, band2, band2_tight); \
+        else hipLaunchKernelGGL((step_tables_kernel<AK, false>), grid, block, 0, s, a, tab32_dev, tab64_dev, tld, band2, band2_tight); \
+        break;
     switch (action_kind) {
         AQUA_TAB_LAUNCH(AQUA_ACT_U8)
         AQUA_TAB_LAUNCH(AQUA_ACT_I32)

@@ -238,12 +238,12 @@ def committed_traffic(n, args):
 
 def per_world_tables(torch, np, presets, BatchedAqua, n, dev):
     """separate line: every world with its own obstacle list (BENCH8, each obstacle moved by up to +-3 units per
-    world), one step launch + one masked-reset launch per step in a HIP graph of 100 steps.  Algorithmic bytes per
+    world), same-step restart inside the step launch, HIP graph of 100 steps.  Algorithmic bytes per
     world-step: 62 + 24 per obstacle row read (6 float32 per row)."""
     rng = np.random.RandomState(7)
     tables = np.repeat(presets.BENCH8[None], n, axis=0).astype(np.float64)
     tables[:, :, 0:2] += rng.uniform(-3, 3, (n, 8, 2))
-    env = BatchedAqua(n, obstacles=tables, seed=0, auto_reset=False, device=dev)
+    env = BatchedAqua(n, obstacles=tables, seed=0, auto_reset="same_step", device=dev)
     env.reset()
     g = torch.Generator(device=dev).manual_seed(99)
     actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=g, dtype=torch.int64).to(torch.uint8)
@@ -260,10 +260,10 @@ def per_world_tables(torch, np, presets, BatchedAqua, n, dev):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * CHUNK)
     a_bytes = A_DISCRETE + 24 * 8
-    return {"env_steps_per_s": n / us * 1e6, "us_per_step": us, "launches_per_step": 2,
+    return {"env_steps_per_s": n / us * 1e6, "us_per_step": us, "launches_per_step": 1,
             "algorithmic_bytes_per_world_step": a_bytes, "achieved_GBps": a_bytes * n / us / 1e3,
             "frac_of_8TBps": a_bytes * n / us / 1e3 / HBM_PEAK_GBPS,
-            "note": "per-world obstacle tables [K][6][N] float32, restart by a masked reset launch after every step"}
+            "note": "per-world obstacle tables [K][6][N] float32, finished worlds restarted inside the step launch (same-step)"}
 
 
 def extras(env, torch, n, a_bytes):

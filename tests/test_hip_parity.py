@@ -398,8 +398,12 @@ def test_per_world_tables_equal_the_shared_table_when_all_worlds_hold_the_same_l
     assert torch.equal(shared.done_mask(), mine.done_mask())
 
 
-def test_per_world_tables_same_step_restart_is_a_masked_reset(torch):
-    """auto_reset='same_step' with per-world tables == step() followed by reset(mask=term) by hand, bit for bit."""
+def test_per_world_tables_same_step_restart_is_a_masked_reset_with_the_steps_tick(torch):
+    """auto_reset='same_step' with per-world tables (restart inside the step launch, 8 lanes per finished world) ==
+    step() followed by the masked reset launch (mask = term, draws of the step's tick) by hand, bit for bit; the
+    masked reset itself is pinned to the oracle in the tests below."""
+    import ctypes
+    from aquaticgymenv_amd import _capi
     n, K = 30000 + 5, 5
     rng = np.random.RandomState(4)
     tables = _random_tables(rng, n, K)
@@ -410,12 +414,19 @@ def test_per_world_tables_same_step_restart_is_a_masked_reset(torch):
     ended = 0
     for _ in range(25):
         act = torch.randint(0, 3, (n,), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+        tick = hand._tick
         _, r1, t1 = auto.step(act)
         _, r2, t2 = hand.step(act)
-        hand.reset(mask=t2)
+        _capi.check(_capi.lib.aqua_reset_tables_f32(ctypes.byref(hand.params), hand._tab32.data_ptr(), hand.K, hand.ld, n,
+                                                    hand.env_offset, hand.state.data_ptr(), hand.ld, hand.time.data_ptr(),
+                                                    hand.term.data_ptr(), hand.seed, tick, None, hand._stream()),
+                    "aqua_reset_tables_f32")
+        _capi.check(_capi.lib.aqua_obs_norm_f32(hand.state.data_ptr(), hand.ld, n, hand.term.data_ptr(), hand._norm_ptr(),
+                                                hand._stream()), "aqua_obs_norm_f32")
         assert torch.equal(t1, t2) and torch.equal(r1, r2)
+        assert torch.equal(auto.done_mask(), hand.done_mask())
         ended += int((t1 != 0).sum())
-    assert torch.equal(auto.state, hand.state) and torch.equal(auto.time, hand.time)
+    assert torch.equal(auto.state[:, :n], hand.state[:, :n]) and torch.equal(auto.time[:n], hand.time[:n])
     assert torch.equal(auto.obs_norm, hand.obs_norm) and ended > n // 10 and int(auto.time[:n].min()) >= 0
 
 
