@@ -1827,6 +1827,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
     if (rc) return rc;
     if (T < 0 || action_step_stride < 0 || out_step_stride < 0 || done_step_stride < 0)
         return fail(AQUA_E_INVALID, "negative T or stride");
+    if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
     if (N == 0 || T == 0) return 0;
     a.action_ld = action_ld; a.auto_reset = auto_reset; a.obs_norm = obs_norm;
     const size_t esz = action_elem_bytes(action_kind);
@@ -1855,6 +1856,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     rc = check_step_buffers(N, actions, action_kind, action_ld, nullptr, 0, reward, term);
     if (rc) return rc;
     if (T < 0 || action_step_stride < 0 || out_step_stride < 0) return fail(AQUA_E_INVALID, "negative T or stride");
+    if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
     if (N == 0 || T == 0) return 0;
     a.action = actions; a.action_ld = action_ld; a.action_step_stride = action_step_stride;
     a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;

@@ -41,8 +41,9 @@ class DoneMaskExchange(object):
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = dist.is_available() and dist.is_initialized()   # a 1-rank group still runs the collective
+        self.world = dist.get_world_size(group) if self.collective else 1
+        self.rank = dist.get_rank(group) if self.collective else 0
         self.steps, self.words = int(steps), int(words)
         self.device = torch.device(device)
         nbuf = 2 if double_buffer else 1
@@ -71,7 +72,7 @@ class DoneMaskExchange(object):
         self._slot = (self._slot + 1) % len(self.gathered)
         self.wait(slot)                       # the buffer we are about to overwrite must have been consumed
         out = self.gathered[slot]
-        if self.world == 1:
+        if not self.collective:
             if self._side is not None:
                 self._side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._side):

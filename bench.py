@@ -11,13 +11,21 @@ Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quote
 obstacles, waves on, Philox noise, auto-reset on.  N > 1: the same batch PER GPU (weak scaling),
 range-partitioned global world indices, done-mask all-gather over RCCL on a side stream.
 
-Steps are queued as replays of a captured HIP graph of CHUNK steps (+ a remainder of eager
-launches so that exactly K steps are timed).  Inputs are resident in HBM before the timed region.
-One JSON line is printed by rank 0.
+Protocol: W untimed warm-up steps, then REGIONS (5) timed regions of EXACTLY K
+steps each, every region bracketed by barrier + torch.cuda.synchronize() on both sides and reduced
+with MAX over the ranks; the MEDIAN region is the one reported (`value`, `ms_per_step`; all five are
+listed under `regions_ms`).  Steps are queued as replays of captured HIP graphs of min(CHUNK, K) steps
+(+ one graph for the remainder), so that any K >= 1 and W >= 0 runs the same way.  Inputs are resident
+in HBM before the timed regions.  Rank 0 prints ONE JSON line.
+
+The CPU baselines (`cpu_baseline*`, oracle/ = test infrastructure, never the product path) run BEFORE
+the process touches the GPU: their worker processes are started with fork+exec, which must not happen
+from a process that has initialised HIP.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,11 +36,12 @@ if ROOT not in sys.path:
 A_DISCRETE = 62      # algorithmic bytes per world-step, SURVEY.md 8(d): 33 read + 29 written
 A_CONTINUOUS = 69
 HBM_PEAK_GBPS = 8000.0
-CHUNK = 100          # steps per captured HIP graph
-GATHER_EVERY = 5     # graphs per done-mask all-gather (N > 1): one [500][words] block per exchange
+CHUNK = 100          # steps per captured HIP graph (at most)
+GATHER_EVERY = 5     # chunks per done-mask block: one [GATHER_EVERY * CHUNK][words] all-gather per block (N > 1)
+REGIONS = 5          # timed regions; the median is reported
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -44,48 +53,151 @@ def parse():
     ap.add_argument("--reset-mode", type=int, default=2, choices=(1, 2),
                     help="restart of finished worlds: 2 = during the next step (default, fastest), 1 = inside the same launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH CPU baseline leg")
+    ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
-    ap.add_argument("--vec", type=int, default=0, help="worlds per lane (0 = auto)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the done-mask exchange (side stream, double buffer) even on one GPU: rehearsal of the N > 1 path")
-    ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel and a 16M-world point")
+    ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel (separate line)")
     ap.add_argument("--per-world-tables", action="store_true",
                     help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.steps < 1:
+        ap.error("--steps must be >= 1")
+    if args.warmup < 0:
+        ap.error("--warmup must be >= 0")
+    if args.regions < 1:
+        ap.error("--regions must be >= 1")
+    return args
 
 
-def run_steps(env, graphs, actions, n_steps, exchange, hist, state):
-    """exactly n_steps batched steps.  Full chunks replay captured graphs; every GATHER_EVERY chunks the
-    [GATHER_EVERY * CHUNK][words] block of done masks they wrote is all-gathered on the side stream
-    (double-buffered: the step stream only waits for the gather that last read the buffer it is about to
-    overwrite, i.e. the one queued two blocks ago)."""
-    full, rem = divmod(n_steps, CHUNK)
-    for _ in range(full):
-        c = state["chunk"]
-        buf, w = (c // GATHER_EVERY) & 1, c % GATHER_EVERY
-        if exchange is not None and w == 0:
-            exchange.wait_source(buf)
-        if graphs is not None:
-            graphs[buf][w].launch()
-        else:
-            env.rollout(CHUNK, actions=actions, keep_all=False, done_history=hist[buf][w * CHUNK:(w + 1) * CHUNK])
-        if exchange is not None and w == GATHER_EVERY - 1:
-            exchange.gather_async(hist[buf], source_id=buf)
-        state["chunk"] = c + 1
-    if rem:
-        env.rollout(rem, actions=actions, keep_all=False)
+# ------------------------------------------------------------------ the step queue (host logic; tests/test_bench_logic.py)
+def plan_region(n_steps, chunk=CHUNK, block_rows=CHUNK * GATHER_EVERY):
+    """Segments covering exactly n_steps, starting at done-mask buffer 0, row 0:
+    [(buf, row0, steps, gather_after)].  A segment is one graph launch (or one C-side launch loop) of
+    `steps` <= chunk steps that writes its done masks to rows [row0, row0 + steps) of buffer `buf`;
+    gather_after marks the segment that completes a block (or the region): the block is exchanged behind it."""
+    if n_steps < 0 or chunk < 1 or block_rows < chunk:
+        raise ValueError("bad plan: n_steps=%d chunk=%d block_rows=%d" % (n_steps, chunk, block_rows))
+    segs, buf, row, left = [], 0, 0, n_steps
+    while left > 0:
+        s = min(chunk, left, block_rows - row)
+        row += s
+        left -= s
+        full = row == block_rows
+        segs.append((buf, row - s, s, full or left == 0))
+        if full:
+            buf, row = buf ^ 1, 0
+    return segs
 
 
-def cpu_baseline(args, obstacles):
-    """the CPU path timed beside the GPU number, on this host's cores (rank 0, N=1 only):
-    'port'   = the reference-style one-world-per-object numpy port (oracle.ScalarPort), 1 core;
-    'port_c' = the float64 C oracle driving float32 state, OpenMP over all cores."""
+class StepRunner(object):
+    """Queues regions of batched steps on `env` (anything with BatchedAqua's rollout()/capture_rollout()).
+
+    Every region starts at buffer 0 / row 0 of the double-buffered done-mask history `hist`, so the segments
+    of a region depend on its length only and their graphs can be captured ahead of the timed code
+    (prepare()).  With an `exchange` (DoneMaskExchange) each completed block is all-gathered on the side
+    stream; the step stream only waits for the gather that last read the buffer it is about to overwrite."""
+
+    def __init__(self, env, actions, hist, exchange=None, use_graph=True, chunk=CHUNK):
+        self.env, self.actions, self.hist, self.exchange = env, actions, hist, exchange
+        self.use_graph, self.chunk = use_graph, chunk
+        self.block_rows = int(hist[0].shape[0])
+        self.graphs = {}
+        self.steps_run = 0
+
+    def plan(self, n_steps):
+        return plan_region(n_steps, self.chunk, self.block_rows)
+
+    def prepare(self, n_steps):
+        if not self.use_graph:
+            return
+        for buf, row0, s, _ in self.plan(n_steps):
+            key = (buf, row0, s)
+            if key not in self.graphs:
+                self.graphs[key] = self.env.capture_rollout(s, actions=self.actions, keep_all=False,
+                                                            done_history=self.hist[buf][row0:row0 + s])
+
+    def run(self, n_steps):
+        """exactly n_steps steps; returns the segments it queued"""
+        segs = self.plan(n_steps)
+        for buf, row0, s, gather_after in segs:
+            if self.exchange is not None and row0 == 0:
+                self.exchange.wait_source(buf)
+            if self.use_graph:
+                self.graphs[(buf, row0, s)].launch()
+            else:
+                self.env.rollout(s, actions=self.actions, keep_all=False, done_history=self.hist[buf][row0:row0 + s])
+            if self.exchange is not None and gather_after:
+                self.exchange.gather_async(self.hist[buf], source_id=buf)
+            self.steps_run += s
+        return segs
+
+    @property
+    def launch(self):
+        return "hipGraph" if self.use_graph else "eager"
+
+
+def pick_median(values):
+    """index of the median element (the lower one of the two middle elements for an even count)"""
+    order = sorted(range(len(values)), key=lambda i: values[i])
+    return order[(len(values) - 1) // 2]
+
+
+def episodes_ended(hist, segs, np):
+    """done flags set in the rows the given segments wrote (popcount of the ballot words)"""
+    total = 0
+    for buf, row0, s, _ in segs:
+        words = hist[buf][row0:row0 + s]
+        words = words.cpu().numpy() if hasattr(words, "cpu") else np.asarray(words)
+        total += int(np.bitwise_count(np.ascontiguousarray(words).view(np.uint64)).sum())
+    return total
+
+
+# ------------------------------------------------------------------ CPU baselines (oracle/: the checker, timed beside the GPU)
+def _port_worker(job):
+    obstacles, continuous, budget_s, seed = job
+    from oracle.aqua_oracle import time_scalar_port
+    return time_scalar_port(obstacles, continuous, budget_s=budget_s, seed=seed)
+
+
+def cpu_baselines(args, obstacles):
+    """Timed on this host's cores, rank 0 at N = 1 only, bounded samples of the same workload (random actions,
+    reset on done, the same obstacle set):
+      cpu_baseline       reference-style port (oracle.ScalarPort: one world per Python object, numpy float64, the
+                         reference's operation sequence, gym_aqua/envs/aqua.py:135-213) on ALL cores, one process per
+                         core with independent worlds -- the loop of main/testing/__init__.py:17-36 under multiprocessing;
+      cpu_baseline_1core the same port on one core;
+      cpu_baseline_c     the float64 C restatement (oracle/aqua_oracle.c) over 262 144 worlds, OpenMP on all cores.
+    Must run before the process initialises HIP (worker processes are forked + exec'd)."""
+    import multiprocessing as mp
     import numpy as np
     from oracle.aqua_oracle import COracle, time_scalar_port
-    steps, secs = time_scalar_port(obstacles, args.continuous, budget_s=args.cpu_seconds)
-    base = {"value": steps / secs, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d random-action steps of ONE world (reset on done), oracle.ScalarPort, %.1f s" % (steps, secs)}
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    budget = float(args.cpu_seconds)
+    steps1, secs1 = time_scalar_port(obstacles, args.continuous, budget_s=min(budget, 5.0))
+    one = {"value": steps1 / secs1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": "%d random-action steps of ONE world (reset on done), oracle.ScalarPort, %.1f s" % (steps1, secs1)}
+    # one process per core; ProcessPoolExecutor so that a worker that cannot start raises instead of hanging
+    from concurrent.futures import ProcessPoolExecutor
+    try:
+        with ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:
+            list(pool.map(_port_worker, [(obstacles, args.continuous, 0.05, 100 + i) for i in range(cores)],
+                          timeout=300))                                       # workers up, imports done
+            t0 = time.perf_counter()
+            parts = list(pool.map(_port_worker, [(obstacles, args.continuous, budget, i) for i in range(cores)],
+                                  timeout=budget + 300))
+            wall = time.perf_counter() - t0
+        steps_all = sum(p[0] for p in parts)
+        allc = {"value": steps_all / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                "sample": "%d random-action steps over %d independent worlds, one process per core (multiprocessing), "
+                          "oracle.ScalarPort (reset on done), %.1f s wall" % (steps_all, cores, wall)}
+    except Exception as exc:                                                  # report the one-core figure, say why
+        allc = dict(one, sample=one["sample"] + " [all-cores leg failed: %s: %s]" % (type(exc).__name__, exc))
     orc = COracle()
     n = 262144
     st = np.zeros((7, n), dtype=np.float32)
@@ -94,24 +206,18 @@ def cpu_baseline(args, obstacles):
     orc.rollout_f32(st, tt, 2, obstacles=obstacles, continuous=args.continuous, seed=0, tick0=1)
     t0 = time.perf_counter()
     T, done = 0, 0.0
-    while done < min(args.cpu_seconds, 8.0):
+    while done < min(budget, 8.0):
         orc.rollout_f32(st, tt, 10, obstacles=obstacles, continuous=args.continuous, seed=0, tick0=3 + T)
         T += 10
         done = time.perf_counter() - t0
     c = {"value": n * T / done, "unit": "env-steps/s", "cores": orc.threads(), "kind": "port",
          "sample": "%d steps of %d worlds, C float64 oracle (oracle/aqua_oracle.c) with OpenMP, %.1f s" % (T, n, done)}
-    return base, c
+    return allc, one, c
 
 
-def main():
-    args = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from aquaticgymenv_amd import _capi, presets
-    from aquaticgymenv_amd.batched import BatchedAqua
-    from aquaticgymenv_amd.sharded import DoneMaskExchange
-
+# ------------------------------------------------------------------ main
+def main(argv=None):
+    args = parse(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,120 +226,160 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
         args.gpus = world
+
+    from aquaticgymenv_amd import presets
+    obstacles = presets.NONE if args.no_obstacles else presets.BENCH8
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baselines(args, obstacles)          # before anything touches the GPU (see the docstring)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from aquaticgymenv_amd.batched import BatchedAqua
+    from aquaticgymenv_amd.sharded import DoneMaskExchange
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    if args.vec:
-        _capi.lib.aqua_set_vector_width(args.vec)
 
     n = args.envs
-    obstacles = presets.NONE if args.no_obstacles else presets.BENCH8
     env = BatchedAqua(n, obstacles=obstacles, continuous=args.continuous, seed=0, env_offset=rank * n,
                       auto_reset=0 if args.no_auto_reset else args.reset_mode, device=dev)
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    chunk = min(CHUNK, max(args.steps, 1))
     if args.continuous:
         actions = torch.rand((CHUNK, 2, env.ld), device=dev, generator=gen) * 0.3 + 0.2
     else:
         actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=gen, dtype=torch.int64).to(torch.uint8)
     words = env.ld // 64
-    hist = [torch.zeros((GATHER_EVERY * CHUNK, words), dtype=torch.int64, device=dev) for _ in range(2)]
-    exchange = DoneMaskExchange(GATHER_EVERY * CHUNK, words, dev) if (world > 1 or args.force_exchange) else None
-    graph = None
-    if not args.eager:
-        graph = [[env.capture_rollout(CHUNK, actions=actions, keep_all=False,
-                                      done_history=hist[b][w * CHUNK:(w + 1) * CHUNK]) for w in range(GATHER_EVERY)]
-                 for b in range(2)]
-    progress = {"chunk": 0}
+    block_rows = GATHER_EVERY * CHUNK
+    hist = [torch.zeros((block_rows, words), dtype=torch.int64, device=dev) for _ in range(2)]
+    exchange = DoneMaskExchange(block_rows, words, dev) if (world > 1 or args.force_exchange) else None
+    runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk)
+    runner.prepare(args.warmup)
+    runner.prepare(args.steps)
 
-    run_steps(env, graph, actions, args.warmup, exchange, hist, progress)
-    if exchange is not None:
-        exchange.finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    run_steps(env, graph, actions, args.steps, exchange, hist, progress)
-    e1.record()
-    if exchange is not None:
-        exchange.finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    def fence():
+        if exchange is not None:
+            exchange.finish()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    runner.run(args.warmup)
+    fence()
+    x_before = float(env.state[0, :n].double().sum().item())
+    walls, events, segs = [], [], []
+    for _ in range(args.regions):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        segs = runner.run(args.steps)
+        e1.record()
+        fence()
+        walls.append(time.perf_counter() - t0)
+        events.append(e0.elapsed_time(e1))           # ms, on the stream the step kernels are launched on
+    if distributed:
+        tmax = torch.tensor(walls, dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+        walls = [float(v) for v in tmax.cpu()]
 
-    # sanity on the timed work: worlds did move and episodes did end (no cached / skipped work)
-    ended = int((hist[0][:CHUNK].cpu().numpy().view(np.uint64) != 0).sum())
-    assert env._tick >= args.steps + args.warmup and (ended > 0 or args.no_auto_reset)
+    # sanity on the timed work (no cached / skipped work): every step was queued, the worlds moved, and -- with
+    # restarts on -- episodes ended inside the last timed region (reported, not asserted: a one-step region right
+    # after a reset may legitimately end none)
+    expect = args.warmup + args.regions * args.steps
+    if env._tick != expect or runner.steps_run != expect:
+        raise RuntimeError("bench queued %d steps (env tick %d), expected %d" % (runner.steps_run, env._tick, expect))
+    x_after = float(env.state[0, :n].double().sum().item())
+    if not (x_after != x_before):
+        raise RuntimeError("the worlds did not move during the timed regions (x checksum %r -> %r)" % (x_before, x_after))
+    ended = episodes_ended(hist, segs, np)
 
     result = None
     if rank == 0:
         a_bytes = A_CONTINUOUS if args.continuous else A_DISCRETE
+        mid = pick_median(walls)
+        wall = walls[mid]
         steps_per_s = world * n * args.steps / wall
-        # the step kernel is the only kernel in the timed stream: its average launch period on the
-        # launch stream (HIP events, boundary gaps included -> a lower bound on the kernel's own rate)
-        launch_s = ev_ms * 1e-3 / args.steps
+        # the step kernel is the only kernel in the timed stream: its average launch period on the launch stream
+        # (HIP events around the region: inter-kernel boundaries and the event-to-first-kernel gap included, so
+        # this is an upper bound of the kernel's own duration); median over the regions
+        launch_s = statistics.median(events) * 1e-3 / args.steps
         achieved = a_bytes * n / launch_s / 1e9
+        traffic, traffic_src = committed_traffic(n, args)
         result = {
             "metric": "env-steps/sec at batch=262144; achieved HBM GB/s vs roofline; 1/2/4/8-GPU scaling",
             "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch %d worlds/GPU, %s actions, %s, waves on, auto-reset (%s), HIP graph of %d steps"
+            "regions": args.regions, "regions_ms": [w * 1e3 for w in walls], "region_reported": "median",
+            "config": {"workload": "batch %d worlds/GPU, %s actions, %s, waves on, auto-reset (%s), %s of <= %d steps"
                        % (n, "continuous f32x2" if args.continuous else "discrete u8",
                           "no obstacles" if args.no_obstacles else "4 circle + 4 rect obstacles",
-                          "off" if args.no_auto_reset else ("next-step" if args.reset_mode == 2 else "same-step"), CHUNK),
+                          "off" if args.no_auto_reset else ("next-step" if args.reset_mode == 2 else "same-step"),
+                          "HIP graphs" if runner.use_graph else "eager launch loops", chunk),
                        "baseline_config": "configs[3]" if args.continuous else ("configs[1]-like" if args.no_obstacles else "configs[2]"),
                        "worlds_per_gpu": n, "global_worlds": world * n, "parallelism": "range-partition x%d" % world,
-                       "launch": "eager" if args.eager else "hipGraph"},
+                       "launch": runner.launch, "done_mask_exchange": exchange is not None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
-                         "note": "launch_us = HIP-event time of the timed region / launches (includes the "
-                                 "inter-kernel boundary); kernel-only duration: profiles/"},
+                         "launch_us_regions": [e * 1e3 / args.steps for e in events],
+                         "note": "launch_us = HIP-event time of a timed region / its launches (median region; includes "
+                                 "the inter-kernel boundary); kernel-only duration: profiles/"},
+            "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended},
         }
-        result["roofline"]["traffic"] = committed_traffic(n, args)
-        if world == 1 and not args.no_cpu_baseline:
-            base, c = cpu_baseline(args, obstacles)
-            result["cpu_baseline"] = base
-            result["cpu_baseline_c"] = c
+        if cpu is not None:
+            result["cpu_baseline"], result["cpu_baseline_1core"], result["cpu_baseline_c"] = cpu
         if args.extras and world == 1:
             result["extras"] = extras(env, torch, n, a_bytes)
         if args.per_world_tables and world == 1:
             result.setdefault("extras", {})["per_world_tables"] = per_world_tables(torch, np, presets, BatchedAqua, n, dev)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return result
 
 
+def library_tag():
+    """sha256 (first 16 hex digits) of the loaded libaqua_hip.so: ties a committed profile to a build"""
+    import hashlib
+    from aquaticgymenv_amd import _capi
+    try:
+        with open(_capi.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
 def committed_traffic(n, args):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE in separate passes, KB -> bytes, FETCH_SIZE doubled: on gfx950 it reports half of a
-    coalesced stream, MI355X_MICROARCH.md "HBM").  null when no profile matches this configuration."""
+    """(HBM bytes per launch, source) from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate passes, KB -> bytes, FETCH_SIZE doubled: on gfx950 it reports half of a coalesced
+    stream, MI355X_MICROARCH.md "HBM").  The counters cannot be read from inside this process, so the figure is
+    a committed measurement of the SAME build: (None, reason) when no row matches this configuration or the row's
+    build tag is not the loaded library's."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)
     except Exception:
-        return None
+        return None, "no profiles/traffic.json"
     key = "n%d_%s_%s" % (n, "cont" if args.continuous else "disc", "k0" if args.no_obstacles else "k8")
     row = table.get(key)
     if not row:
-        return None
-    return 2.0 * row["FETCH_SIZE_per_launch_raw"] * 1024.0 + row["WRITE_SIZE_per_launch_raw"] * 1024.0
+        return None, "no committed PMC pass for " + key
+    tag = library_tag()
+    if row.get("library_sha16") != tag:
+        return None, "committed PMC pass %s is of build %s, this is %s" % (row.get("source"), row.get("library_sha16"), tag)
+    return (2.0 * row["FETCH_SIZE_per_launch_raw"] * 1024.0 + row["WRITE_SIZE_per_launch_raw"] * 1024.0,
+            "%s (build %s)" % (row.get("source"), tag))
 
 
 def per_world_tables(torch, np, presets, BatchedAqua, n, dev):

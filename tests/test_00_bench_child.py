@@ -1,0 +1,81 @@
+"""bench.py end to end on the GPU, as the driver runs it: in a FRESH child process, with the driver's own flags.
+
+This file sorts first on purpose: the children are started (fork + exec) before this pytest process has made its
+first HIP call -- a process that has initialised the GPU must not be the one that execs on the GPU boxes.  Nothing
+here touches the GPU in-process (torch.cuda.device_count() does not initialise it)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, "rc %d\n--- stdout\n%s\n--- stderr\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line expected, got %d:\n%s" % (len(lines), p.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+def _check_line(r, steps, warmup):
+    assert r["steps"] == steps and r["warmup"] == warmup and r["n_gpus"] == 1
+    assert r["unit"] == "env-steps/s" and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["value"] > 1.0e7, "below the 10 M env-steps/s target: %r" % r["value"]
+    assert abs(r["value"] - 262144 * steps / (r["ms_per_step"] * 1e-3 * steps)) <= 1e-6 * r["value"]
+    assert r["config"]["baseline_config"] == "configs[2]" and "262144" in r["config"]["workload"]
+    assert r["config"]["launch"] == "hipGraph"
+    assert len(r["regions_ms"]) == r["regions"] == 5
+    assert sorted(r["regions_ms"])[2] == pytest.approx(r["ms_per_step"] * steps)
+    roof = r["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"])
+    assert roof["achieved"] == pytest.approx(62 * 262144 / (roof["launch_us"] * 1e-6) / 1e9)
+    assert 0.05 < roof["frac"] < 1.0
+    assert "traffic" in roof and "traffic_source" in roof
+    assert r["sanity"]["steps_queued"] == warmup + 5 * steps
+    assert r["sanity"]["episodes_ended_last_region"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_with_the_drivers_flags_in_a_child_process():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (round 1's driver command, which asserted) prints the line"""
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1"])
+    _check_line(r, 20, 5)
+    for key in ("cpu_baseline", "cpu_baseline_1core", "cpu_baseline_c"):
+        b = r[key]
+        assert b["value"] > 0 and b["unit"] == "env-steps/s" and b["kind"] == "port" and b["cores"] >= 1 and b["sample"]
+    assert r["cpu_baseline"]["cores"] >= r["cpu_baseline_1core"]["cores"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_odd_step_counts_in_a_child_process():
+    """one step without warm-up, and a count that needs full chunks + a remainder"""
+    r = _run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r["steps"] == 1 and r["sanity"]["steps_queued"] == 5
+    r = _run([sys.executable, "bench.py", "--steps", "230", "--warmup", "7", "--no-cpu-baseline"])
+    _check_line(r, 230, 7)
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_executes_the_rccl_branch():
+    """one rank under torch.distributed.run: init_process_group("nccl"), the barriers, the MAX all-reduce of the region
+    times and the done-mask all_gather_into_tensor (RCCL, side stream, double buffer) all execute on the device.
+    No 1 -> 8 GPU curve is measured here: the driver does that on an 8-GPU node."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "120", "--warmup", "5",
+              "--no-cpu-baseline", "--force-exchange"])
+    _check_line(r, 120, 5)
+    assert r["config"]["done_mask_exchange"] is True

@@ -1,0 +1,144 @@
+"""bench.py's host logic on the CPU: the step queue (chunks, remainder, done-mask blocks, exchange hand-offs) with a
+stub environment -- any --steps >= 1 / --warmup >= 0 must queue exactly that many steps, write the done masks of
+every one of them, and label the launch mode by what was actually timed.  (Round 1's bench crashed on the driver's
+`--steps 20 --warmup 5`: the remainder path wrote no done history.)"""
+import numpy as np
+import pytest
+
+import bench
+
+
+class StubGraph(object):
+    def __init__(self, env, steps, done_history):
+        self.env, self.steps, self.done_history = env, steps, done_history
+
+    def launch(self):
+        self.env._do(self.steps, self.done_history, "graph")
+
+
+class StubEnv(object):
+    """records what bench.StepRunner asks for; every step sets one bit in its done-mask row"""
+
+    def __init__(self):
+        self._tick = 0
+        self.captured = []
+        self.calls = []
+
+    def _do(self, steps, done_history, how):
+        assert done_history is not None and done_history.shape[0] == steps, "every step needs a done-mask row"
+        for i in range(steps):
+            done_history[i, 0] = self._tick + i + 1          # nonzero: episodes "ended"
+        self._tick += steps
+        self.calls.append((how, steps))
+
+    def capture_rollout(self, steps, actions=None, keep_all=False, done_history=None):
+        assert steps >= 1
+        self.captured.append(steps)
+        return StubGraph(self, steps, done_history)
+
+    def rollout(self, steps, actions=None, keep_all=False, done_history=None):
+        self._do(steps, done_history, "eager")
+
+
+class StubExchange(object):
+    def __init__(self):
+        self.log = []
+
+    def wait_source(self, buf):
+        self.log.append(("wait", buf))
+
+    def gather_async(self, block, source_id=None):
+        self.log.append(("gather", source_id))
+
+
+def _hist(rows=bench.CHUNK * bench.GATHER_EVERY, words=4):
+    return [np.zeros((rows, words), dtype=np.int64) for _ in range(2)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 20, 99, 100, 101, 250, 499, 500, 501, 1234, 2000])
+def test_plan_covers_exactly_n_steps(n):
+    segs = bench.plan_region(n)
+    assert sum(s for _, _, s, _ in segs) == n
+    rows = bench.CHUNK * bench.GATHER_EVERY
+    seen = {}
+    for buf, row0, s, gather in segs:
+        assert 1 <= s <= bench.CHUNK and 0 <= row0 and row0 + s <= rows and buf in (0, 1)
+        assert gather == (row0 + s == rows or (buf, row0, s, gather) == segs[-1])
+    # rows of one block are written once per pass over it, in order
+    buf, row = 0, 0
+    for b, row0, s, _ in segs:
+        assert (b, row0) == (buf, row)
+        row += s
+        if row == rows:
+            buf, row = buf ^ 1, 0
+    if n:
+        assert segs[-1][3], "the last segment of a region is always exchanged"
+    del seen
+
+
+def test_plan_rejects_nonsense():
+    with pytest.raises(ValueError):
+        bench.plan_region(-1)
+    with pytest.raises(ValueError):
+        bench.plan_region(10, chunk=0)
+
+
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (1, 0), (100, 100), (101, 7), (2000, 200), (37, 0), (600, 1)])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_runner_queues_exactly_the_requested_steps(steps, warmup, use_graph):
+    env, hist = StubEnv(), _hist()
+    chunk = min(bench.CHUNK, steps)
+    r = bench.StepRunner(env, None, hist, None, use_graph=use_graph, chunk=chunk)
+    r.prepare(warmup)
+    r.prepare(steps)
+    n_graphs = len(env.captured)
+    r.run(warmup)
+    assert env._tick == warmup
+    for region in range(3):
+        segs = r.run(steps)
+        assert env._tick == warmup + (region + 1) * steps
+        assert bench.episodes_ended(hist, segs, np) > 0           # every segment wrote its rows
+        assert sum(s for _, _, s, _ in segs) == steps
+    assert r.steps_run == warmup + 3 * steps
+    assert len(env.captured) == n_graphs, "no graph may be captured inside a timed region"
+    assert all(how == ("graph" if use_graph else "eager") for how, _ in env.calls)
+    assert r.launch == ("hipGraph" if use_graph else "eager")
+    if use_graph:
+        assert max(env.captured) <= chunk
+
+
+def test_runner_exchange_handoffs():
+    """a block is gathered behind the segment that completes it (or the region); the step stream waits for the gather
+    that last read a buffer before the first segment that overwrites it"""
+    env, hist, ex = StubEnv(), _hist(), StubExchange()
+    r = bench.StepRunner(env, None, hist, ex, use_graph=True, chunk=bench.CHUNK)
+    r.prepare(1234)
+    r.run(1234)          # 500 (buf 0) + 500 (buf 1) + 234 (buf 0)
+    assert ex.log == [("wait", 0), ("gather", 0), ("wait", 1), ("gather", 1), ("wait", 0), ("gather", 0)]
+    ex.log.clear()
+    r.prepare(20)
+    r.run(20)
+    assert ex.log == [("wait", 0), ("gather", 0)]
+
+
+def test_median_pick():
+    assert bench.pick_median([5.0]) == 0
+    assert bench.pick_median([3.0, 1.0, 2.0]) == 2
+    assert bench.pick_median([9.0, 1.0, 5.0, 7.0, 3.0]) == 2
+    assert bench.pick_median([4.0, 1.0, 3.0, 2.0]) == 3          # lower of the two middle elements (2.0)
+
+
+def test_argument_checks():
+    assert bench.parse(["--steps", "20", "--warmup", "5"]).steps == 20
+    assert bench.parse([]).regions == bench.REGIONS
+    for bad in (["--steps", "0"], ["--warmup", "-1"], ["--regions", "0"]):
+        with pytest.raises(SystemExit):
+            bench.parse(bad)
+
+
+def test_traffic_is_null_without_a_matching_build(monkeypatch):
+    """roofline.traffic comes from a committed PMC pass of the SAME build or is null with the reason"""
+    args = bench.parse([])
+    monkeypatch.setattr(bench, "library_tag", lambda: "0" * 16)
+    traffic, src = bench.committed_traffic(262144, args)
+    assert traffic is None and isinstance(src, str) and src
