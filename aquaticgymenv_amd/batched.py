@@ -22,12 +22,13 @@ def _round_up(n, m):
 class RolloutGraph(object):
     """A captured HIP graph of T batched steps (+ the device tick bump); replay with launch()."""
 
-    def __init__(self, env, handle, steps, reward, term):
+    def __init__(self, env, handle, steps, reward, term, events=None):
         self._env = env
         self._handle = handle
         self.steps = steps
         self.reward = reward
         self.term = term
+        self._events = events             # (start, stop) AquaEvent handles recorded as nodes of the graph, or None
 
     def launch(self):
         env = self._env
@@ -37,10 +38,23 @@ class RolloutGraph(object):
         env._device_tick += self.steps
         return self.reward, self.term
 
+    def elapsed_ms(self):
+        """GPU time of the last replay between the graph's first and last node (capture_rollout(timing=True)); the
+        stream must have been synchronised since."""
+        if self._events is None:
+            raise RuntimeError("captured without timing=True")
+        ms = ctypes.c_float(0.0)
+        _capi.check(_capi.lib.aqua_event_elapsed_ms(self._events[0], self._events[1], ctypes.byref(ms)), "aqua_event_elapsed_ms")
+        return float(ms.value)
+
     def close(self):
         if self._handle is not None:
             _capi.lib.aqua_graph_destroy(self._handle)
             self._handle = None
+        if self._events is not None:
+            for e in self._events:
+                _capi.lib.aqua_event_destroy(e)
+            self._events = None
 
     def __del__(self):
         try:
@@ -353,9 +367,10 @@ class BatchedAqua(object):
         self._tick += steps
         return reward, term
 
-    def capture_rollout(self, steps, actions=None, fused=False, keep_all=False, done_history=None):
+    def capture_rollout(self, steps, actions=None, fused=False, keep_all=False, done_history=None, timing=False):
         """Capture `steps` batched steps into a HIP graph.  Noise stays fresh across replays: the
-        kernels add a device-resident tick base that the graph's last node advances by `steps`."""
+        kernels add a device-resident tick base that the graph's last node advances by `steps`.
+        timing=True: the graph starts and ends with an event-record node (RolloutGraph.elapsed_ms())."""
         torch = self.torch
         aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld)
         reward, term, ostride = self._rollout_out(steps, keep_all)
@@ -365,6 +380,11 @@ class BatchedAqua(object):
         cap = torch.cuda.Stream(device=self.device)
         cap.wait_stream(torch.cuda.current_stream(self.device))
         handle = ctypes.c_void_p()
+        events = None
+        if timing:
+            events = (ctypes.c_void_p(), ctypes.c_void_p())
+            for e in events:
+                _capi.check(lib.aqua_event_create(ctypes.byref(e)), "aqua_event_create")
         with torch.cuda.device(self.device), torch.cuda.stream(cap):
             s = self._stream()
             _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
@@ -385,11 +405,14 @@ class BatchedAqua(object):
                 if rc == 0:
                     rc = lib.aqua_tick_advance(tb, steps, s)
             finally:
-                rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
+                if timing:
+                    rc_end = lib.aqua_graph_end_timed(s, ctypes.byref(handle), events[0], events[1])
+                else:
+                    rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
             _capi.check(rc, "capture rollout")
             _capi.check(rc_end, "aqua_graph_end")
         torch.cuda.current_stream(self.device).wait_stream(cap)
-        g = RolloutGraph(self, handle, steps, reward, term)
+        g = RolloutGraph(self, handle, steps, reward, term, events)
         g._actions = actions          # keep the action buffer alive as long as the graph
         g.done_history = done if dstride else None
         return g

@@ -35,6 +35,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/aqua_hip.h"
 #include "aqua_device.hpp"
@@ -621,10 +622,10 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const uint64_t world = static_cast<uint64_t>(a.env_offset + tile) + i;
             EnvState e;
             if constexpr (QUICK == QUICK_ALWAYS && AQUA_STEP_RESEED_QUICK)
-                e = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
-                                                               k.K, k.obst, nullptr, k.quick, k.Kc);
+                e = reseed_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                            k.K, k.obst, nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
             else
-                e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+                e = reseed_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
                 st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
                 st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -766,7 +767,7 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     // the time row -- and the obstacle pass of the re-seeding reads them from there after the barrier below,
     // four rows per wait (through the scalar path it waits once per two rows, 200 clocks each).
 #ifndef AQUA_NS_RESEED_QUICK                // 1: small tables are read from the quick table (SGPR operands) instead of LDS
-#define AQUA_NS_RESEED_QUICK 0
+#define AQUA_NS_RESEED_QUICK (AQUA_RESEED_IMPL == 2)
 #endif
     constexpr bool reseed_quick = SMALL_TABLE && AQUA_NS_RESEED_QUICK;
     constexpr bool table_in_regs = SMALL_TABLE && !reseed_quick;
@@ -818,12 +819,12 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         const uint64_t env = static_cast<uint64_t>(a.env_offset + base) + i;
         EnvState e;
         if constexpr (reseed_quick)
-            e = reset_env_group<NS_RESEED_GROUP, RESEED_QUICK>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst,
-                                                               nullptr, k.quick, k.Kc);
+            e = reseed_group<NS_RESEED_GROUP, RESEED_QUICK>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst,
+                                                            nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
         else if constexpr (SMALL_TABLE)
-            e = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
+            e = reseed_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
         else
-            e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            e = reseed_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
             st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
             st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -835,8 +836,15 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     AQUA_RTSTAMP(2);
 }
 
+// Five blocks of a CU (one re-seeding, four stepping at 262 144 worlds) must be resident TOGETHER: the grid is exactly
+// one round of blocks, and a kernel that needs more than 512 / 5 registers per lane leaves some blocks waiting for a
+// slot (a second round: +0.5 us per launch, measured with 82 registers -> 88 allocated -> 5 wavefronts per SIMD and
+// not one to spare).  Asking for at least 6 wavefronts per SIMD caps the kernel at 80 registers.
+#ifndef AQUA_NS_WAVES_PER_EU
+#define AQUA_NS_WAVES_PER_EU 6
+#endif
 template <int AK, bool SMALL_TABLE>
-__global__ __launch_bounds__(NS_BLOCK) void step_ns_kernel(const StepArgs a)
+__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_NS_WAVES_PER_EU, 8))) void step_ns_kernel(const StepArgs a)
 {
     AQUA_OBST_DECL
     __shared__ NsReseedShared sh;
@@ -1040,10 +1048,10 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepA
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
         EnvState f;
         if constexpr (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER)
-            f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
-                                                           k.K, k.obst, nullptr, k.quick, k.Kc);
+            f = reseed_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                        k.K, k.obst, nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
         else
-            f = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            f = reseed_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.result[q];
             r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
@@ -1268,7 +1276,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32, nullptr, tld, tile + i};
-            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
+            const EnvState f = reseed_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
                                                                           tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
                                                                           nullptr, nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1348,7 +1356,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
         for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
         const int64_t i = base + (active ? sh.list[seg][q - first[seg]] : 0);      // an idle group reads a world that exists
         const WorldTable wt{t32, nullptr, tld, i};
-        const EnvState e = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
+        const EnvState e = reseed_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
                                                                       a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
                                                                       nullptr, 0, &wt);
         if (active && (lane & (RESET_GROUP - 1)) == 0) store(i, e);
@@ -1591,6 +1599,10 @@ struct AquaGraph {
     hipGraphExec_t exec;
 };
 
+struct AquaEvent {
+    hipEvent_t event;
+};
+
 extern "C" {
 
 int aqua_version(void) { return AQUA_ABI_VERSION; }
@@ -1684,14 +1696,19 @@ void aqua_discrete_constants(float out[9])
 __global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, int iters)
 {
     AQUA_OBST_DECL
-    const StepConst k = make_const(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<QUICK_IF_PRESENT>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
     float acc = 0.0f;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int rep = 0; rep < 2; ++rep) {          // rep 0 warms the instruction and scalar caches
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
         for (int it = 0; it < iters; ++it) {
-            const EnvState e = reset_env_group<RESET_GROUP>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
-                                                            a.tick + it, k.waves, 1, 1, k.K, k.obst);
+            EnvState e;
+            if (k.quick != nullptr)
+                e = reseed_group<RESET_GROUP, RESEED_QUICK>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
+                                                            a.tick + it, k.waves, 1, 1, k.K, k.obst, nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
+            else
+                e = reseed_group<RESET_GROUP>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
+                                              a.tick + it, k.waves, 1, 1, k.K, k.obst);
             acc += e.x + e.gy;
         }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -1701,6 +1718,12 @@ __global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, i
             acc += u_01(r[0] ^ r[3]);
         }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+        for (int it = 0; it < iters; ++it) {
+            uint32_t w0, w1;
+            draw_pair(a.seed, (threadIdx.x >> 1) + 64ull * it, a.tick, STREAM_PLACE, 0, (threadIdx.x & 1) != 0, w0, w1);
+            acc += u_01(w0 ^ w1);
+        }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3)::"memory");
     }
     // exact path: first (cold instruction cache) call vs later calls, one wavefront
     unsigned long long e0, e1, e2, e3;
@@ -1717,7 +1740,7 @@ __global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, i
                    k.obst, k.band2, k.time_limit);
     acc += o.x;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e3)::"memory");
-    if (threadIdx.x == 0) { out[0] = (t1 - t0) / iters; out[1] = (t2 - t1) / iters; out[3] = e1 - e0; out[4] = e2 - e1; out[5] = e3 - e2; }
+    if (threadIdx.x == 0) { out[0] = (t1 - t0) / iters; out[1] = (t2 - t1) / iters; out[6] = (t3 - t2) / iters; out[3] = e1 - e0; out[4] = e2 - e1; out[5] = e3 - e2; }
     if (acc == 12345.678f) out[2] = 1;
 }
 
@@ -2071,6 +2094,70 @@ int aqua_graph_destroy(AquaGraph* g)
     (void)hipGraphExecDestroy(g->exec);
     (void)hipGraphDestroy(g->graph);
     delete g;
+    return 0;
+}
+
+int aqua_event_create(AquaEvent** out)
+{
+    if (out == nullptr) return fail(AQUA_E_INVALID, "out is NULL");
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDefault);
+    if (rc != hipSuccess) return hip_fail(rc, "hipEventCreateWithFlags");
+    *out = new AquaEvent{e};
+    return 0;
+}
+
+int aqua_event_record(AquaEvent* e, void* stream)
+{
+    if (e == nullptr) return fail(AQUA_E_INVALID, "event is NULL");
+    const hipError_t rc = hipEventRecord(e->event, static_cast<hipStream_t>(stream));
+    return rc == hipSuccess ? 0 : hip_fail(rc, "hipEventRecord");
+}
+
+int aqua_graph_end_timed(void* stream, AquaGraph** out, AquaEvent* start, AquaEvent* stop)
+{
+    if (out == nullptr || start == nullptr || stop == nullptr) return fail(AQUA_E_INVALID, "out/start/stop is NULL");
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(static_cast<hipStream_t>(stream), &g);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+    // event-record nodes around what was captured: `start` ahead of every root, `stop` behind every leaf
+    const auto bail = [&](hipError_t err, const char* what) { (void)hipGraphDestroy(g); return hip_fail(err, what); };
+    size_t n_nodes = 0, n_roots = 0;
+    if ((e = hipGraphGetNodes(g, nullptr, &n_nodes)) != hipSuccess) return bail(e, "hipGraphGetNodes");
+    std::vector<hipGraphNode_t> nodes(n_nodes);
+    if (n_nodes && (e = hipGraphGetNodes(g, nodes.data(), &n_nodes)) != hipSuccess) return bail(e, "hipGraphGetNodes");
+    if ((e = hipGraphGetRootNodes(g, nullptr, &n_roots)) != hipSuccess) return bail(e, "hipGraphGetRootNodes");
+    std::vector<hipGraphNode_t> roots(n_roots), leaves;
+    if (n_roots && (e = hipGraphGetRootNodes(g, roots.data(), &n_roots)) != hipSuccess) return bail(e, "hipGraphGetRootNodes");
+    for (hipGraphNode_t node : nodes) {
+        size_t n_dep = 0;
+        if ((e = hipGraphNodeGetDependentNodes(node, nullptr, &n_dep)) != hipSuccess) return bail(e, "hipGraphNodeGetDependentNodes");
+        if (n_dep == 0) leaves.push_back(node);
+    }
+    hipGraphNode_t first = nullptr, last = nullptr;
+    if ((e = hipGraphAddEventRecordNode(&first, g, nullptr, 0, start->event)) != hipSuccess) return bail(e, "hipGraphAddEventRecordNode");
+    for (hipGraphNode_t root : roots)
+        if ((e = hipGraphAddDependencies(g, &first, &root, 1)) != hipSuccess) return bail(e, "hipGraphAddDependencies");
+    if ((e = hipGraphAddEventRecordNode(&last, g, leaves.data(), leaves.size(), stop->event)) != hipSuccess)
+        return bail(e, "hipGraphAddEventRecordNode");
+    hipGraphExec_t x = nullptr;
+    if ((e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0)) != hipSuccess) return bail(e, "hipGraphInstantiate");
+    *out = new AquaGraph{g, x};
+    return 0;
+}
+
+int aqua_event_elapsed_ms(AquaEvent* start, AquaEvent* stop, float* ms)
+{
+    if (start == nullptr || stop == nullptr || ms == nullptr) return fail(AQUA_E_INVALID, "event/ms is NULL");
+    const hipError_t rc = hipEventElapsedTime(ms, start->event, stop->event);
+    return rc == hipSuccess ? 0 : hip_fail(rc, "hipEventElapsedTime");
+}
+
+int aqua_event_destroy(AquaEvent* e)
+{
+    if (e == nullptr) return 0;
+    (void)hipEventDestroy(e->event);
+    delete e;
     return 0;
 }
 

@@ -104,19 +104,48 @@ class StepRunner(object):
         self.use_graph, self.chunk = use_graph, chunk
         self.block_rows = int(hist[0].shape[0])
         self.graphs = {}
+        self.timed = set()
+        self.timing_error = None
         self.steps_run = 0
 
     def plan(self, n_steps):
         return plan_region(n_steps, self.chunk, self.block_rows)
 
-    def prepare(self, n_steps):
+    def prepare(self, n_steps, timing=False):
+        """capture the graphs a region of n_steps needs; timing=True: a region that is ONE graph carries event-record
+        nodes at its head and tail (region_graph_ms())"""
         if not self.use_graph:
             return
-        for buf, row0, s, _ in self.plan(n_steps):
+        plan = self.plan(n_steps)
+        for buf, row0, s, _ in plan:
             key = (buf, row0, s)
-            if key not in self.graphs:
-                self.graphs[key] = self.env.capture_rollout(s, actions=self.actions, keep_all=False,
-                                                            done_history=self.hist[buf][row0:row0 + s])
+            timed = timing and len(plan) == 1
+            if key not in self.graphs or (timed and key not in self.timed):
+                done = self.hist[buf][row0:row0 + s]
+                if timed:
+                    try:
+                        self.graphs[key] = self.env.capture_rollout(s, actions=self.actions, keep_all=False,
+                                                                    done_history=done, timing=True)
+                        self.timed.add(key)
+                        continue
+                    except Exception as exc:         # event-record nodes unsupported: the stream events remain
+                        self.timing_error = "%s: %s" % (type(exc).__name__, exc)
+                if key not in self.graphs:
+                    self.graphs[key] = self.env.capture_rollout(s, actions=self.actions, keep_all=False, done_history=done)
+
+    def region_graph_ms(self, segs):
+        """GPU time between the first and the last node of the region's graph (None unless the region was one timed
+        graph); call after the stream has been synchronised"""
+        if not self.use_graph or len(segs) != 1:
+            return None
+        key = segs[0][:3]
+        if key not in self.timed:
+            return None
+        try:
+            return self.graphs[key].elapsed_ms()
+        except Exception as exc:                     # in-graph event records unsupported: the stream events remain
+            self.timing_error = "%s: %s" % (type(exc).__name__, exc)
+            return None
 
     def run(self, n_steps):
         """exactly n_steps steps; returns the segments it queued"""
@@ -161,6 +190,32 @@ def _port_worker(job):
     return time_scalar_port(obstacles, continuous, budget_s=budget_s, seed=seed)
 
 
+def usable_cores():
+    """cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows all
+    of the host's cores in the mask but schedules the container on its share of them)"""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = fields[0], float(fields[1])
+            else:
+                quota = fields[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    period = float(g.read().split()[0])
+            if quota not in ("max", "-1") and float(quota) > 0:
+                cores = max(1, min(cores, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return cores
+
+
 def cpu_baselines(args, obstacles):
     """Timed on this host's cores, rank 0 at N = 1 only, bounded samples of the same workload (random actions,
     reset on done, the same obstacle set):
@@ -173,11 +228,8 @@ def cpu_baselines(args, obstacles):
     import multiprocessing as mp
     import numpy as np
     from oracle.aqua_oracle import COracle, time_scalar_port
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)       # read by libgomp when the C oracle is loaded below
     budget = float(args.cpu_seconds)
     steps1, secs1 = time_scalar_port(obstacles, args.continuous, budget_s=min(budget, 5.0))
     one = {"value": steps1 / secs1, "unit": "env-steps/s", "cores": 1, "kind": "port",
@@ -262,7 +314,7 @@ def main(argv=None):
     exchange = DoneMaskExchange(block_rows, words, dev) if (world > 1 or args.force_exchange) else None
     runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk)
     runner.prepare(args.warmup)
-    runner.prepare(args.steps)
+    runner.prepare(args.steps, timing=True)
 
     def fence():
         if exchange is not None:
@@ -275,7 +327,7 @@ def main(argv=None):
     runner.run(args.warmup)
     fence()
     x_before = float(env.state[0, :n].double().sum().item())
-    walls, events, segs = [], [], []
+    walls, events, graph_ms, segs = [], [], [], []
     for _ in range(args.regions):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -285,6 +337,7 @@ def main(argv=None):
         fence()
         walls.append(time.perf_counter() - t0)
         events.append(e0.elapsed_time(e1))           # ms, on the stream the step kernels are launched on
+        graph_ms.append(runner.region_graph_ms(segs))
     if distributed:
         tmax = torch.tensor(walls, dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -310,7 +363,9 @@ def main(argv=None):
         # the step kernel is the only kernel in the timed stream: its average launch period on the launch stream
         # (HIP events around the region: inter-kernel boundaries and the event-to-first-kernel gap included, so
         # this is an upper bound of the kernel's own duration); median over the regions
-        launch_s = statistics.median(events) * 1e-3 / args.steps
+        stream_us = statistics.median(events) * 1e3 / args.steps
+        in_graph = all(g is not None and g > 0.0 for g in graph_ms)
+        launch_s = (statistics.median(graph_ms) if in_graph else statistics.median(events)) * 1e-3 / args.steps
         achieved = a_bytes * n / launch_s / 1e9
         traffic, traffic_src = committed_traffic(n, args)
         result = {
@@ -330,9 +385,14 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
-                         "launch_us_regions": [e * 1e3 / args.steps for e in events],
-                         "note": "launch_us = HIP-event time of a timed region / its launches (median region; includes "
-                                 "the inter-kernel boundary); kernel-only duration: profiles/"},
+                         "launch_us_regions": [(g if in_graph else e) * 1e3 / args.steps for g, e in zip(graph_ms, events)],
+                         "launch_us_events": "graph nodes" if in_graph else "stream",
+                         "launch_us_stream_events": stream_us, "graph_timing_error": runner.timing_error,
+                         "note": "launch_us = HIP-event time of a timed region / its launches, median region, inter-kernel "
+                                 "boundaries included.  'graph nodes': the region is ONE graph whose first and last node "
+                                 "record the events (no host launch latency inside the interval); 'stream': events recorded "
+                                 "on the launch stream around the region's graph launches (launch_us_stream_events, always "
+                                 "given).  Kernel-only duration: profiles/"},
             "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended},
         }
         if cpu is not None:

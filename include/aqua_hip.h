@@ -213,6 +213,20 @@ int aqua_graph_end(void* stream, AquaGraph** out);
 int aqua_graph_launch(AquaGraph* g, void* stream);
 int aqua_graph_destroy(AquaGraph* g);
 
+/*
+ * Timing events (HIP events).  aqua_event_record() stamps the event when `stream` reaches it.
+ * aqua_graph_end_timed() is aqua_graph_end() with two event-record NODES added to the captured graph -- `start` ahead
+ * of everything captured, `stop` behind it -- so that every replay stamps both and their distance is exactly the
+ * captured launches (bench.py's roofline.launch_us: no host launch latency inside the interval).
+ * aqua_event_elapsed_ms() needs both events recorded and complete (synchronise the stream first).
+ */
+typedef struct AquaEvent AquaEvent;
+int aqua_event_create(AquaEvent** out);
+int aqua_event_record(AquaEvent* e, void* stream);
+int aqua_graph_end_timed(void* stream, AquaGraph** out, AquaEvent* start, AquaEvent* stop);
+int aqua_event_elapsed_ms(AquaEvent* start, AquaEvent* stop, float* ms);
+int aqua_event_destroy(AquaEvent* e);
+
 /* Introspection for tests and bench: which kernel variant a call with these arguments would run. */
 int aqua_step_vector_width(const float* state, int64_t ld, const int32_t* time, const float* reward,
                            const void* action, int action_kind, int64_t action_ld, const float* noise,

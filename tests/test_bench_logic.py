@@ -31,7 +31,7 @@ class StubEnv(object):
         self._tick += steps
         self.calls.append((how, steps))
 
-    def capture_rollout(self, steps, actions=None, keep_all=False, done_history=None):
+    def capture_rollout(self, steps, actions=None, keep_all=False, done_history=None, timing=False):
         assert steps >= 1
         self.captured.append(steps)
         return StubGraph(self, steps, done_history)
@@ -90,7 +90,7 @@ def test_runner_queues_exactly_the_requested_steps(steps, warmup, use_graph):
     chunk = min(bench.CHUNK, steps)
     r = bench.StepRunner(env, None, hist, None, use_graph=use_graph, chunk=chunk)
     r.prepare(warmup)
-    r.prepare(steps)
+    r.prepare(steps, timing=True)
     n_graphs = len(env.captured)
     r.run(warmup)
     assert env._tick == warmup

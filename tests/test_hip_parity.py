@@ -603,6 +603,26 @@ def test_graph_replay_equals_eager(torch, reset_mode):
         assert np.array_equal(a, b)
 
 
+def test_timed_graph_brackets_its_launches(torch):
+    """capture_rollout(timing=True): event-record nodes at the head and the tail of the graph stamp every replay;
+    the interval is the captured launches (bench.py's roofline.launch_us) and the results are the untimed graph's"""
+    from aquaticgymenv_amd import presets
+    n, T = 262144, 20
+    res = []
+    for timing in (False, True):
+        env = _make(torch, n, presets.BENCH8, seed=8, auto_reset=2)
+        env.reset()
+        graph = env.capture_rollout(T, timing=timing)
+        for _ in range(3):
+            graph.launch()
+        torch.cuda.synchronize()
+        if timing:
+            ms = graph.elapsed_ms()
+            assert 0.02 < ms < 2.0, "20 steps of 262 144 worlds take ~0.1 ms on an MI355X, got %r ms" % ms
+        res.append((env.state.cpu().numpy().copy(), env.time.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 # ------------------------------------------------------------------------------------------------
 # layout / shapes
 # ------------------------------------------------------------------------------------------------

@@ -14,5 +14,5 @@ for name, rows in (("bench8", presets.BENCH8), ("none", presets.NONE)):
     f.argtypes = [ctypes.POINTER(_capi.AquaParams), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     _capi.check(f(ctypes.byref(p), dev.data_ptr() if dev is not None else None, rows.shape[0], out.data_ptr(), None), "bench")
     torch.cuda.synchronize()
-    print(name, "reset_env_group: %d cycles/call   philox draw: %d cycles   exact_step 1st/2nd/3rd call: %d / %d / %d cycles" %
-          (int(out[0]), int(out[1]), int(out[3]), int(out[4]), int(out[5])))
+    print(name, "group re-seeding: %d cycles/call   philox draw: %d cycles   pair draw: %d cycles   exact_step 1st/2nd/3rd call: %d / %d / %d cycles" %
+          (int(out[0]), int(out[1]), int(out[6]), int(out[3]), int(out[4]), int(out[5])))
