@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64
@@ -53,7 +53,7 @@ def _load():
                                   vp, ci, vp]
     lib.aqua_reset_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_rollout_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp, vp, vp,
-                                     i64, vp, i64, vp, ci, vp]
+                                     i64, vp, i64, vp, ci, ci, vp]
     lib.aqua_rollout_fused_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp,
                                            vp, vp, i64, ci, vp]
     lib.aqua_tick_advance.argtypes = [vp, u64, vp]

@@ -138,7 +138,7 @@ class BatchedAqua(object):
                 self._blob = host.to(dev)
             else:
                 self._blob = None
-            self._tick_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._tick_dev = torch.zeros(2, dtype=torch.int64, device=dev)      # [0] tick base of captured graphs, [1] scratch
             # optional fused epilogue (main/impl/utils.py:15-33): obs / (high - low), angle + 0.5
             self.obs_norm_buf = torch.zeros((5, self.ld), dtype=torch.float32, device=dev) if normalized_obs else None
         self._tick = 0                    # one per step: draws of the step, and of the restarts the step kernels do
@@ -157,7 +157,7 @@ class BatchedAqua(object):
 
     def _sync_device_tick(self):
         if self._device_tick != self._tick:
-            self._tick_dev.fill_(self._tick)
+            self._tick_dev[0:1].fill_(self._tick)
             self._device_tick = self._tick
 
     @property
@@ -362,7 +362,7 @@ class BatchedAqua(object):
                                                  self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
                                                  steps, aptr, kind, ald, astride, self.seed, self._tick, None,
                                                  reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(),
-                                                 dstride, self._norm_ptr(), int(self.auto_reset), self._stream()),
+                                                 dstride, self._norm_ptr(), int(self.auto_reset), 0, self._stream()),
                             "aqua_rollout_f32")
         self._tick += steps
         return reward, term
@@ -401,8 +401,8 @@ class BatchedAqua(object):
                                               self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
                                               steps, aptr, kind, ald, astride, self.seed, 0, tb, reward.data_ptr(),
                                               term.data_ptr(), ostride, done.data_ptr(), dstride, self._norm_ptr(),
-                                              int(self.auto_reset), s)
-                if rc == 0:
+                                              int(self.auto_reset), 1, s)        # advances the tick base itself
+                if rc == 0 and fused:
                     rc = lib.aqua_tick_advance(tb, steps, s)
             finally:
                 if timing:

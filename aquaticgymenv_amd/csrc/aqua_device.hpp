@@ -16,15 +16,12 @@
 namespace aqua {
 
 constexpr float BAND = 1.0e-4f;          // half-width of the knife-edge band of the plain float32 margins, in world units
-#ifndef AQUA_BAND_TIGHT
-#define AQUA_BAND_TIGHT 2.0e-6f
-#endif
 // ... of the error-compensated margins (second look, see fast_step).  Border and obstacles: what is left after the
 // compensation is the error of the displacement (<= 3.3e-7: hardware sin/cos 3.5e-7 x chord 0.5, the rounded
 // chord and angle, one fma, and the reference's own float64 cancellation on straight moves) plus, for obstacles,
 // the rounding of d^2 (covered by the 4 ulp(R^2) term of the per-obstacle band).  The goal distance goes through
 // two more roundings at magnitude 5 and a hardware sqrt (bound 1.2e-6, largest seen 1.3e-7): it keeps 4e-6.
-constexpr float BAND_TIGHT = AQUA_BAND_TIGHT;
+constexpr float BAND_TIGHT = 2.0e-6f;
 constexpr float BAND_TIGHT_GOAL = 4.0e-6f;
 constexpr int RESET_TRIES = 64;
 constexpr int MAX_OBST = 64;
@@ -79,19 +76,11 @@ __device__ __forceinline__ QuickRects quick_rects(QuickPtr q, int at)
     return QuickRects{q[at], q[at + 1], q[at + 2], q[at + 3], q[at + 4]};
 }
 
-// Where the per-batch obstacle table is read from.  Default: straight from the packed blob through the
-// CONSTANT address space -- every lane reads the same row, so the loads are scalar (s_load_dwordx4 into
-// SGPRs, served by the scalar cache) and the rows cost no VGPRs, no LDS round trip and no barrier.
-// -DAQUA_OBST_LDS=1 builds the variant that stages the table into LDS once per workgroup instead
-// (kept for A/B measurements and as the base of per-world tables; DESIGN.md "Obstacle table").
-#ifndef AQUA_OBST_LDS
-#define AQUA_OBST_LDS 0
-#endif
-#if AQUA_OBST_LDS
-using ObstPtr = const ObstF*;
-#else
+// The per-batch obstacle table is read straight from the packed blob through the CONSTANT address space: every lane
+// reads the same row, so the loads are scalar (s_load_dwordx4 into SGPRs, served by the scalar cache) and the rows cost
+// no VGPRs, no LDS round trip and no barrier (staging the table in LDS per workgroup measured 0.6-1.5 us per step
+// slower; the re-seeding blocks of the next-step kernel, which wait on LDS anyway, do use an LDS copy).
 using ObstPtr = const ObstF __attribute__((address_space(4)))*;
-#endif
 
 struct EnvState {               // registers of one world
     float x, y, th, gx, gy, wx, wy;
@@ -128,19 +117,16 @@ constexpr float ACT_H_LINE = 0x1.12e0bep-29f, ACT_W_LINE = 0x1.12e0bep-28f, ACT_
 // Stream 1 holds the placement attempts of a reset: words 0,1 = goal candidate of attempt a, words 2,3 = boat
 // candidate of attempt a.  Stream 3 (attempt 0): heading, wave x, wave y.
 enum : uint32_t { STREAM_STEP = 0, STREAM_PLACE = 1, STREAM_POSE = 3, STREAM_ACT = 4 };
+constexpr int PHILOX_ROUNDS = 10;
 
 template <bool SCALAR_KEY = false>
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
                                                uint32_t c3, uint32_t (&out)[4])
 {
-#ifndef AQUA_PHILOX_ROUNDS
-#define AQUA_PHILOX_ROUNDS 10
-#endif
-#ifndef AQUA_PHILOX_UNROLL                  // round bodies per loop iteration of the per-lane form (10: fully unrolled)
-#define AQUA_PHILOX_UNROLL 10
-#endif
-#pragma unroll AQUA_PHILOX_UNROLL
-    for (int r = 0; r < AQUA_PHILOX_ROUNDS; ++r) {
+    // fully unrolled: as a loop of 1 / 2 / 5 round bodies the launch is 0.2-0.5 us slower (independent chains no longer
+    // interleave)
+#pragma unroll
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         // one 32x32->64 product per half round (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32:
         // integer multiplies issue at a quarter of the VALU rate and are the bulk of this routine
         const uint64_t p0 = static_cast<uint64_t>(c0) * 0xD2511F53ull;
@@ -178,7 +164,7 @@ __device__ __forceinline__ void philox4x32_10_pair(uint32_t k0, uint32_t k1, uin
     const uint32_t mult = odd ? 0xCD9E8D57u : 0xD2511F53u;
     const uint32_t bump = odd ? 0xBB67AE85u : 0x9E3779B9u;
 #pragma unroll
-    for (int r = 0; r < AQUA_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         const uint64_t prod = static_cast<uint64_t>(m) * mult;
         const uint32_t t = static_cast<uint32_t>(prod >> 32) ^ p;   // odd: hi(M1 c2) ^ c1     even: hi(M0 c0) ^ c3
         m = swap_pair(t) ^ key;                                     // even: .. ^ k0 = c0'     odd: .. ^ k1 = c2'
@@ -375,16 +361,8 @@ __device__ __forceinline__ ObstF world_row(const WorldTable& t, int j)
     return r;
 }
 
-#ifndef AQUA_INLINE_EXACT
-#define AQUA_INLINE_EXACT 0
-#endif
-#if AQUA_INLINE_EXACT
-#define AQUA_EXACT_ATTR __forceinline__
-#else
-#define AQUA_EXACT_ATTR __noinline__
-#endif
 template <bool PER_WORLD>
-__device__ AQUA_EXACT_ATTR ExactOut exact_step_impl(float fx, float fy, float fth, float fgx, float fgy, float fwx,
+__device__ __noinline__ ExactOut exact_step_impl(float fx, float fy, float fth, float fgx, float fgy, float fwx,
                                                  float fwy, int t_new, ExactMotion mo, int K,
                                                  const double* __restrict__ obst64, ObstPtr obst32, float band2,
                                                  int time_limit, WorldTable wt)
@@ -524,13 +502,8 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float xn = e.x + ddx, yn = e.y + ddy;
     const float thn = wrap_add(e.th, w);
     // wave random walk (aqua.py:188-191): drawn after the move
-#ifdef AQUA_EXP_CLAMP_MINMAX                // timing experiment: v_max + v_min instead of v_med3 (same values)
-    const float wxn = fminf(fmaxf(fmaf(u0, k.sigma, e.wx), -k.W), k.W);
-    const float wyn = fminf(fmaxf(fmaf(u1, k.sigma, e.wy), -k.W), k.W);
-#else
     const float wxn = __builtin_amdgcn_fmed3f(fmaf(u0, k.sigma, e.wx), -k.W, k.W);
     const float wyn = __builtin_amdgcn_fmed3f(fmaf(u1, k.sigma, e.wy), -k.W, k.W);
-#endif
     const int tn = e.t + 1;                                // aqua.py:141
 
     const float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
@@ -578,9 +551,6 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float shaped = dsum > 0.0f ? 0.7f * (num * __builtin_amdgcn_rcpf(dsum)) : 0.0f;
 
     bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
-#ifdef AQUA_EXP_NO_SECOND                  // timing experiment only: what the second look (and everything behind it) costs
-    knife = false;
-#endif
     float mc_f = mc, mo_f = mo, mg_f = mg;
     if (__builtin_expect(any_lane(knife), 0)) {
         // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
@@ -773,29 +743,19 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // two Philox chains (placement attempt, heading + wave) of the first round are independent and interleave.  Must be
 // called by all 64 lanes of a wavefront together; `active` says whether this lane's group has a world.
 // Every lane of a group returns the group's result.
-#ifndef AQUA_INLINE_RESEED
-#define AQUA_INLINE_RESEED 1
-#endif
-#if AQUA_INLINE_RESEED
-#define AQUA_RESEED_ATTR __forceinline__
-#else
-#define AQUA_RESEED_ATTR __noinline__
-#endif
+// (inlined: as an out-of-line function a callee-saved VGPR was spilled to scratch, 9.5 -> 9.1 us per step)
 // ROWS > 0: the table (ROWS rows, absent ones with r2 < 0) is read from `rows` in LDS, a few rows at a time, instead
 // of through the scalar path, which waits once per two rows.
 // ROWS == RESEED_QUICK: the table is read from its quick table `quick` (Kc circles first): one scalar-memory round trip
 // per group of four obstacles, and the hit tests are the row tests on the same values (a circle's half extents are
 // the zeros they are in its row; r2 = -(-r2)).
-#ifndef AQUA_RESEED_HALF_BARRIER
-#define AQUA_RESEED_HALF_BARRIER 1
-#endif
 // ROWS == RESEED_WORLD: the table is the group's OWN (per-world tables): `wt` names the world the group re-seeds; its
 // lanes read the same addresses, so a row costs the group one memory transaction per field.  Rows are read two at
 // a time inside the attempt loop (measured: all rows up front, 40 more live registers, made the masked reset
 // launch 10.2 us instead of 8.8; one world per lane with the rows cached: 10 us).
 constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2;
 template <int G, int ROWS = 0>
-__device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
+__device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
                                                      const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
                                                      const WorldTable* wt = nullptr)
@@ -824,9 +784,6 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
         const float cbx = fmaf(95.0f, u_01(rp[2]), 2.5f), cby = fmaf(95.0f, u_01(rp[3]), 2.5f);
         // one pass over the obstacle table tests both candidates of this attempt
         bool hit_g = false, hit_b = false;
-#ifndef AQUA_RESEED_UNROLL
-#define AQUA_RESEED_UNROLL 2
-#endif
         auto test = [&](float cx, float cy, float hx, float hy, float r2) {
             const float gax = fabsf(cgx - cx), gay = fabsf(cgy - cy);
             const float gdx = fmaxf(gax - hx, 0.0f), gdy = fmaxf(gay - hy, 0.0f);
@@ -838,10 +795,7 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
             hit_b |= fmaf(bdx, bdx, bdy2) <= r2;
         };
         if constexpr (ROWS > 0) {                        // `rows` is in LDS: a few rows in registers at a time
-#ifndef AQUA_RESEED_ROWS_PER_STEP
-#define AQUA_RESEED_ROWS_PER_STEP 2
-#endif
-            constexpr int RS = AQUA_RESEED_ROWS_PER_STEP;
+            constexpr int RS = 2;                         // rows in registers at a time
 #pragma unroll
             for (int h = 0; h < ROWS; h += RS) {
                 // (the index is laundered so that the reads stay here, next to their use, instead of being
@@ -856,13 +810,11 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
                 }
 #pragma unroll
                 for (int j = 0; j < RS; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
-#if AQUA_RESEED_HALF_BARRIER
                 // finish these rows before the next ones are read: without it the vectoriser pairs operations
                 // across ALL rows and keeps the whole table (and sixteen partial results) live at once
                 uint32_t fg = hit_g, fb = hit_b;
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
-#endif
             }
         } else if constexpr (ROWS == RESEED_WORLD) {
             for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
@@ -889,7 +841,7 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
                 if (K - Kc > 4) rects(quick_rects(quick, QUICK_R1));
             }
         } else {
-#pragma unroll AQUA_RESEED_UNROLL
+#pragma unroll 2
             for (int j = 0; j < K; ++j) test(t[j].cx, t[j].cy, t[j].hx, t[j].hy, t[j].r2);
         }
         // goal: lowest accepted attempt of the group (aqua.py:103-105)
@@ -912,9 +864,6 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
         const float sbx = __shfl(cbx, bsrc), sby = __shfl(cby, bsrc);
         if (goal_found && !boat_done && !serial && bm) { bx = sbx; by = sby; bt = heading; boat_done = true; }
         if (!any_lane((!goal_found || !boat_done) && !serial)) break;
-#ifdef AQUA_EXP_ONE_ROUND                  // timing experiment only: what the later rounds of the re-seeding cost
-        break;
-#endif
     }
     // goal attempts exhausted: the goal stays at its fixed default (aqua.py:107) and the boat is still scanned
     if (active && random_boat && !boat_done && !goal_found) serial = true;
@@ -947,329 +896,6 @@ __device__ AQUA_RESEED_ATTR EnvState reset_env_group(bool active, uint64_t seed,
     e.wy = W * u_pm1(rw[2]);
     e.t = 0;
     return e;
-}
-
-
-// ------------------------------------------------------------------------------------ reset, pair-cooperative groups
-// The same specification once more, and the form every kernel uses to re-seed finished worlds: G adjacent lanes per
-// world = G / 2 PAIRS, and a pair owns one placement attempt per round.  The two lanes of a pair compute the
-// attempt's Philox block together (philox4x32_10_pair: one quarter-rate multiply per lane and round instead of two),
-// and its words fall where the specification wants them -- the even lane receives words 0,1 = the attempt's GOAL
-// candidate, the odd lane words 2,3 = its BOAT candidate -- so every lane tests exactly ONE candidate against the
-// obstacle table.  Against reset_env_group (G lanes = G attempts, every lane a whole block, both candidates and the
-// whole pose block): half the multiplies per draw, half the hit tests, the pose block as a pair draw too; a round
-// is ~1 300 issue cycles instead of ~2 700.
-//
-// Order of the serial specification (reset_env): goal = first accepted goal candidate, attempts 0..63, else the fixed
-// goal; boat = first boat candidate, attempts 0..63, that is clear of the FINAL goal and of the obstacles, else the
-// fixed pose.  A group keeps one attempt base per phase:
-//   goal phase   pairs test attempts base .. base + G/2 - 1; the lowest accepted one is the goal.  Found in the first
-//                round (base 0): the boat candidates of that same round have been scanned in order with the final goal
-//                and count.  Found later: the boat scan restarts at attempt 0 (boat phase, base 0) -- the earlier
-//                rounds' boat candidates were never judged.  64 attempts rejected: the fixed goal, boat phase from 0.
-//   boat phase   the lowest accepted boat candidate of the round, else base += G/2; 64 rejected: the fixed pose.
-// No lane ever scans alone (reset_env_group's serial fallback is gone); groups of one wavefront may be in different
-// phases.  All 64 lanes must call it together (DPP pair exchange).  The result is complete in the group's FIRST lane.
-template <int G, int ROWS = 0>
-__device__ __forceinline__ EnvState reset_env_pairs(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
-                                                    int random_boat, int random_goal, int K, ObstPtr t,
-                                                    const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
-                                                    const WorldTable* wt = nullptr)
-{
-#pragma clang fp contract(off)
-    static_assert(G >= 4 && G <= 64 && (G & (G - 1)) == 0, "group size");
-    constexpr uint32_t A = G / 2;                         // attempts per round
-    static_assert(RESET_TRIES % A == 0, "rounds cover the attempts exactly");
-    constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
-    K = uni(K); t = uni_ptr(t); seed = uni(seed); tick = uni(tick);
-    waves = uni(waves); random_boat = uni(random_boat); random_goal = uni(random_goal);
-    const int lane = static_cast<int>(threadIdx.x) & 63;
-    const int sub = lane & (G - 1), gbase = lane & ~(G - 1);
-    const bool odd = (sub & 1) != 0;
-    const uint32_t pair = static_cast<uint32_t>(sub) >> 1;
-    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    // pose block (heading, wave x | wave y, unused): one pair draw, every pair of the group holds the same halves
-    uint32_t q0, q1;
-    draw_pair(seed, env, tick, STREAM_POSE, 0, odd, q0, q1);
-    const float W = 0.05f * static_cast<float>(waves);
-    const float heading = fmaf(TWO_PI_F, u_01(q0), -PI_F);            // even lanes: word 0
-    const float wave_a = W * u_pm1(odd ? q0 : q1);                     // even lanes: word 1 = wave x; odd lanes: word 2 = wave y
-    const float wave_y = __builtin_bit_cast(float, swap_pair(__builtin_bit_cast(uint32_t, wave_a)));   // the partner's
-
-    float gx = 25.0f, gy = 80.0f, bx = 85.0f, by = 45.0f, bt = 0.0f;  // aqua.py:107,117
-    bool goal_found = !active || !random_goal;
-    bool boat_done = !active || !random_boat;
-    uint32_t base = 0;                                                // group-uniform
-    // the first round's draw is issued here, beside the pose draw: two independent chains that interleave
-    uint32_t w0, w1;
-    draw_pair(seed, env, tick, STREAM_PLACE, pair, odd, w0, w1);
-    while (any_lane(!goal_found || !boat_done)) {
-        const float cx = fmaf(95.0f, u_01(w0), 2.5f), cy = fmaf(95.0f, u_01(w1), 2.5f);   // even: goal candidate, odd: boat candidate
-        bool hit = false;
-        auto test = [&](float ox, float oy, float hx, float hy, float r2) {
-            const float ax = fabsf(cx - ox), ay = fabsf(cy - oy);
-            const float dx = fmaxf(ax - hx, 0.0f), dy = fmaxf(ay - hy, 0.0f);
-            const float dy2 = dy * dy;
-            hit |= fmaf(dx, dx, dy2) <= r2;
-        };
-        if constexpr (ROWS > 0) {                         // `rows` is in LDS (absent rows: r2 < 0, never hit)
-#pragma unroll
-            for (int h = 0; h < ROWS; h += 2) {
-                int first_row = h;                        // laundered: the reads stay next to their use
-                asm volatile("" : "+v"(first_row));
-                const ObstF* r = rows + first_row;
-                float c[2][5];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { c[j][0] = r[j].cx; c[j][1] = r[j].cy; c[j][2] = r[j].hx; c[j][3] = r[j].hy; c[j][4] = r[j].r2; }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
-                // finish these rows before the next ones are read: without it the vectoriser pairs operations across
-                // ALL rows and keeps the whole table (and eight partial results) live at once
-                uint32_t f = hit;
-                asm volatile("" : "+v"(f));
-                hit = f != 0u;
-            }
-        } else if constexpr (ROWS == RESEED_WORLD) {
-            for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
-                const ObstF r0 = world_row(*wt, j), r1 = world_row(*wt, j + 1 < K ? j + 1 : j);
-                test(r0.cx, r0.cy, r0.hx, r0.hy, r0.r2);
-                test(r1.cx, r1.cy, r1.hx, r1.hy, r1.r2);
-            }
-        } else if constexpr (ROWS == RESEED_QUICK) {
-            const auto circles = [&](const QuickCircles& g) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) test(g.cx[j], g.cy[j], 0.0f, 0.0f, -g.nr2[j]);
-            };
-            const auto rects = [&](const QuickRects& g) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) test(g.cx[j], g.cy[j], g.hx[j], g.hy[j], -g.nr2[j]);
-            };
-            Kc = uni(Kc); quick = uni_ptr(quick);
-            if (Kc > 0) {
-                circles(quick_circles(quick, QUICK_C0));
-                if (Kc > 4) circles(quick_circles(quick, QUICK_C1));
-            }
-            if (K - Kc > 0) {
-                rects(quick_rects(quick, QUICK_R0));
-                if (K - Kc > 4) rects(quick_rects(quick, QUICK_R1));
-            }
-        } else {
-#pragma unroll 2
-            for (int j = 0; j < K; ++j) test(t[j].cx, t[j].cy, t[j].hx, t[j].hy, t[j].r2);
-        }
-        // goal phase: the lowest accepted goal candidate of the round (aqua.py:103-105)
-        const uint64_t gm = (__ballot(!odd && !goal_found && !hit) >> gbase) & gmask;
-        const int gsrc = gm ? gbase + __builtin_ctzll(gm) : lane;
-        const float sgx = __shfl(cx, gsrc), sgy = __shfl(cy, gsrc);
-        const bool found_now = !goal_found && gm != 0;
-        const bool late_goal = found_now && base != 0;    // the boat scan restarts at attempt 0
-        if (found_now) { gx = sgx; gy = sgy; goal_found = true; }
-        // boat phase (aqua.py:111-115), also in the round that found the goal at base 0
-        const float ex = gx - cx, ey = gy - cy;
-        const float ey2 = ey * ey;
-        const float g2 = fmaf(ex, ex, ey2);
-        const bool scan_boat = goal_found && !boat_done && !late_goal;
-        const uint64_t bm = (__ballot(odd && scan_boat && !(g2 <= 25.0f) && !hit) >> gbase) & gmask;
-        const int bsrc = bm ? gbase + __builtin_ctzll(bm) : lane;
-        const float sbx = __shfl(cx, bsrc), sby = __shfl(cy, bsrc);
-        if (scan_boat && bm) { bx = sbx; by = sby; bt = heading; boat_done = true; }
-        // next round of this group
-        if (late_goal) base = 0;
-        else if (!goal_found || !boat_done) {
-            base += A;
-            if (base >= static_cast<uint32_t>(RESET_TRIES)) {
-                if (!goal_found) { goal_found = true; base = 0; }     // fixed goal (aqua.py:107); the boat is still scanned
-                else boat_done = true;                                  // fixed pose (aqua.py:117)
-            }
-        }
-        if (!any_lane(!goal_found || !boat_done)) break;
-        draw_pair(seed, env, tick, STREAM_PLACE, base + pair, odd, w0, w1);
-    }
-    EnvState e;
-    e.x = bx; e.y = by; e.th = bt; e.gx = gx; e.gy = gy;
-    e.wx = wave_a;                                        // first lane of the group is even: wave x
-    e.wy = wave_y;
-    e.t = 0;
-    return e;
-}
-
-// ------------------------------------------------------------------------------------ reset, one attempt per lane, packed tests
-// reset_env_group's layout (G lanes per world, lane `sub` owns attempt base + sub: the whole placement block, i.e. the
-// goal AND the boat candidate) rewritten for LATENCY: a re-seeding wavefront runs while its neighbours wait for memory,
-// so what it costs the launch is the length of its dependent chain, not its instruction count (the
-// pair-cooperative form above halves the instructions and is slower).  What is different here:
-//   * the two candidates of a lane are tested TOGETHER with packed float32 operations (v_pk_add / v_pk_mul / v_pk_fma
-//     on the pair (goal candidate, boat candidate)): 6 operations per circle, 12 per rectangle, for both candidates,
-//     instead of 2 x 9..12.  max(|d| - h, 0) is formed as max3(d - h, -d - h, 0): the same roundings, the same bits;
-//   * a table of at most four circles and four rectangles is the caller's quick-table groups in SGPRs (loaded with the
-//     table header at the top of the kernel): no load and no wait inside the chain;
-//   * the goal and the boat are picked in ONE cross-lane round trip: the first obstacle-free boat candidate is fetched
-//     together with the first accepted goal candidate, and only when it turns out to lie within the goal's circle
-//     (0.9 % of the worlds) is the boat scan repeated with the goal known;
-//   * the rounds use reset_env_pairs' attempt-base bookkeeping (goal phase / boat phase, a late goal restarts the boat
-//     scan at attempt 0), so no lane ever scans alone.
-// Same specification, same bits as reset_env().  All 64 lanes call it together; the result is complete in every lane
-// of the group.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int G, int ROWS = 0>
-__device__ __forceinline__ EnvState reset_env_lanes(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
-                                                    int random_boat, int random_goal, int K, ObstPtr t,
-                                                    const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
-                                                    const WorldTable* wt = nullptr, const QuickCircles* c0 = nullptr,
-                                                    const QuickRects* r0 = nullptr)
-{
-#pragma clang fp contract(off)
-    static_assert(G >= 2 && G <= 64 && (G & (G - 1)) == 0, "group size");
-    static_assert(RESET_TRIES % G == 0, "rounds cover the attempts exactly");
-    constexpr float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
-    K = uni(K); t = uni_ptr(t); seed = uni(seed); tick = uni(tick);
-    waves = uni(waves); random_boat = uni(random_boat); random_goal = uni(random_goal);
-    const int lane = static_cast<int>(threadIdx.x) & 63;
-    const int sub = lane & (G - 1), gbase = lane & ~(G - 1);
-    const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    uint32_t rp[4], rw[4];
-    draw(seed, env, tick, STREAM_PLACE, static_cast<uint32_t>(sub), rp);   // two independent chains: they interleave
-    draw(seed, env, tick, STREAM_POSE, 0, rw);
-    const float W = 0.05f * static_cast<float>(waves);
-    const float heading = fmaf(TWO_PI_F, u_01(rw[0]), -PI_F);
-
-    float gx = 25.0f, gy = 80.0f, bx = 85.0f, by = 45.0f, bt = 0.0f;      // aqua.py:107,117
-    bool goal_found = !active || !random_goal;
-    bool boat_done = !active || !random_boat;
-    uint32_t base = 0;                                                    // group-uniform
-    while (any_lane(!goal_found || !boat_done)) {
-        // .x: the goal candidate of this lane's attempt, .y: its boat candidate
-        const f32x2 X = {fmaf(95.0f, u_01(rp[0]), 2.5f), fmaf(95.0f, u_01(rp[2]), 2.5f)};
-        const f32x2 Y = {fmaf(95.0f, u_01(rp[1]), 2.5f), fmaf(95.0f, u_01(rp[3]), 2.5f)};
-        bool hit_g = false, hit_b = false;
-        const auto circle = [&](float ox, float oy, float r2) {           // |d| - 0 clamped at 0, squared: d * d
-            const f32x2 dx = X - ox, dy = Y - oy;
-            const f32x2 dy2 = dy * dy;
-            const f32x2 d2 = __builtin_elementwise_fma(dx, dx, dy2);
-            hit_g |= d2.x <= r2; hit_b |= d2.y <= r2;
-        };
-        const auto box = [&](float ox, float oy, float hx, float hy, float r2) {
-            const f32x2 dx = X - ox, dy = Y - oy;
-            const f32x2 px = dx - hx, nx = -dx - hx, py = dy - hy, ny = -dy - hy;
-            const f32x2 mx = {fmaxf(fmaxf(px.x, nx.x), 0.0f), fmaxf(fmaxf(px.y, nx.y), 0.0f)};
-            const f32x2 my = {fmaxf(fmaxf(py.x, ny.x), 0.0f), fmaxf(fmaxf(py.y, ny.y), 0.0f)};
-            const f32x2 dy2 = my * my;
-            const f32x2 d2 = __builtin_elementwise_fma(mx, mx, dy2);
-            hit_g |= d2.x <= r2; hit_b |= d2.y <= r2;
-        };
-        if constexpr (ROWS == RESEED_QUICK) {
-            Kc = uni(Kc); quick = uni_ptr(quick);
-            const auto circles = [&](const QuickCircles& g) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) circle(g.cx[j], g.cy[j], -g.nr2[j]);
-            };
-            const auto rects = [&](const QuickRects& g) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) box(g.cx[j], g.cy[j], g.hx[j], g.hy[j], -g.nr2[j]);
-            };
-            if (Kc > 0) {
-                circles(c0 != nullptr ? *c0 : quick_circles(quick, QUICK_C0));
-                if (Kc > 4) circles(quick_circles(quick, QUICK_C1));
-            }
-            if (K - Kc > 0) {
-                rects(r0 != nullptr ? *r0 : quick_rects(quick, QUICK_R0));
-                if (K - Kc > 4) rects(quick_rects(quick, QUICK_R1));
-            }
-        } else if constexpr (ROWS > 0) {                  // `rows` is in LDS (absent rows: r2 < 0, never hit)
-#pragma unroll
-            for (int h = 0; h < ROWS; h += 2) {
-                int first_row = h;                        // laundered: the reads stay next to their use
-                asm volatile("" : "+v"(first_row));
-                const ObstF* r = rows + first_row;
-                float c[2][5];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { c[j][0] = r[j].cx; c[j][1] = r[j].cy; c[j][2] = r[j].hx; c[j][3] = r[j].hy; c[j][4] = r[j].r2; }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) box(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
-                uint32_t fg = hit_g, fb = hit_b;          // finish these rows before the next ones are read
-                asm volatile("" : "+v"(fg), "+v"(fb));
-                hit_g = fg != 0u; hit_b = fb != 0u;
-            }
-        } else if constexpr (ROWS == RESEED_WORLD) {
-            for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
-                const ObstF r0w = world_row(*wt, j), r1w = world_row(*wt, j + 1 < K ? j + 1 : j);
-                box(r0w.cx, r0w.cy, r0w.hx, r0w.hy, r0w.r2);
-                box(r1w.cx, r1w.cy, r1w.hx, r1w.hy, r1w.r2);
-            }
-        } else {
-#pragma unroll 2
-            for (int j = 0; j < K; ++j) box(t[j].cx, t[j].cy, t[j].hx, t[j].hy, t[j].r2);
-        }
-        // the lowest accepted goal candidate (aqua.py:103-105) and the lowest obstacle-free boat candidate of the round,
-        // fetched together
-        const uint64_t gm = (__ballot(!goal_found && !hit_g) >> gbase) & gmask;
-        const uint64_t cm = (__ballot(!hit_b) >> gbase) & gmask;
-        const int gsrc = gm ? gbase + __builtin_ctzll(gm) : lane;
-        const int csrc = cm ? gbase + __builtin_ctzll(cm) : lane;
-        const float sgx = __shfl(X.x, gsrc), sgy = __shfl(Y.x, gsrc);
-        float sbx = __shfl(X.y, csrc), sby = __shfl(Y.y, csrc);
-        const bool found_now = !goal_found && gm != 0;
-        const bool late_goal = found_now && base != 0;    // the boat scan restarts at attempt 0
-        if (found_now) { gx = sgx; gy = sgy; goal_found = true; }
-        const bool scan_boat = goal_found && !boat_done && !late_goal;
-        bool have = cm != 0;
-        {
-            const float ex = gx - sbx, ey = gy - sby;     // aqua.py:111-115: not on the goal
-            const float ey2 = ey * ey;
-            const bool near = fmaf(ex, ex, ey2) <= 25.0f;
-            if (__builtin_expect(any_lane(scan_boat && have && near), 0)) {
-                // the first free candidate lies on the goal: scan again with the goal known (all lanes take part in the
-                // exchange; only the groups concerned use it)
-                const float ox = gx - X.y, oy = gy - Y.y;
-                const float oy2 = oy * oy;
-                const bool far = !(fmaf(ox, ox, oy2) <= 25.0f);
-                const uint64_t bm = (__ballot(!hit_b && far) >> gbase) & gmask;
-                const int bsrc = bm ? gbase + __builtin_ctzll(bm) : lane;
-                const float tbx = __shfl(X.y, bsrc), tby = __shfl(Y.y, bsrc);
-                if (near) { sbx = tbx; sby = tby; have = bm != 0; }
-            }
-        }
-        if (scan_boat && have) { bx = sbx; by = sby; bt = heading; boat_done = true; }
-        // next round of this group
-        if (late_goal) base = 0;
-        else if (!goal_found || !boat_done) {
-            base += G;
-            if (base >= static_cast<uint32_t>(RESET_TRIES)) {
-                if (!goal_found) { goal_found = true; base = 0; }     // fixed goal (aqua.py:107); the boat is still scanned
-                else boat_done = true;                                  // fixed pose (aqua.py:117)
-            }
-        }
-        if (!any_lane(!goal_found || !boat_done)) break;
-        draw(seed, env, tick, STREAM_PLACE, base + static_cast<uint32_t>(sub), rp);
-    }
-    EnvState e;
-    e.x = bx; e.y = by; e.th = bt; e.gx = gx; e.gy = gy;
-    e.wx = W * u_pm1(rw[1]);
-    e.wy = W * u_pm1(rw[2]);
-    e.t = 0;
-    return e;
-}
-
-// what the kernels call.  AQUA_RESEED_IMPL: 2 reset_env_lanes (default), 1 reset_env_pairs, 0 reset_env_group (round 1);
-// the same results bit for bit, kept selectable for A/B timing (tools/ab.py)
-#ifndef AQUA_RESEED_IMPL
-#define AQUA_RESEED_IMPL 2
-#endif
-template <int G, int ROWS = 0>
-__device__ __forceinline__ EnvState reseed_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
-                                                 int random_boat, int random_goal, int K, ObstPtr t,
-                                                 const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
-                                                 const WorldTable* wt = nullptr, const QuickCircles* c0 = nullptr,
-                                                 const QuickRects* r0 = nullptr)
-{
-#if AQUA_RESEED_IMPL == 2
-    return reset_env_lanes<G, ROWS>(active, seed, env, tick, waves, random_boat, random_goal, K, t, rows, quick, Kc, wt, c0, r0);
-#elif AQUA_RESEED_IMPL == 1
-    return reset_env_pairs<G, ROWS>(active, seed, env, tick, waves, random_boat, random_goal, K, t, rows, quick, Kc, wt);
-#else
-    return reset_env_group<G, ROWS>(active, seed, env, tick, waves, random_boat, random_goal, K, t, rows, quick, Kc, wt);
-#endif
 }
 
 }  // namespace aqua

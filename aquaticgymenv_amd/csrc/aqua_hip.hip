@@ -14,25 +14,17 @@
 // All of it is coalesced float/integer streaming work on struct-of-arrays rows; no MFMA anywhere (there is
 // no contraction to feed it).  Arithmetic shared by the kernels lives in aqua_device.hpp.
 //
-// Build-time switches (-D, all optional; tools/ab.py times variants against each other on one box):
-//   tuning      AQUA_NS_MAIN_WAVES (4) wavefronts per block of the next-step kernel; AQUA_NS_SCAN_ROWS (4) x 256 worlds
-//               scanned per re-seeding block; AQUA_NS_RESEED_GROUP (8) lanes per restarting world; AQUA_NS_TABLE_ROWS (8)
-//               largest table read from LDS by the re-seeding pass; AQUA_NS_RESEED_PRIO (3); AQUA_RESEED_ROWS_PER_STEP,
-//               AQUA_RESEED_UNROLL, AQUA_TILE, AQUA_RESET_GROUP, AQUA_STORE_HINT / AQUA_LOAD_HINT (cache scopes),
-//               AQUA_OBST_LDS, AQUA_INLINE_RESEED, AQUA_INLINE_EXACT, AQUA_BAND_TIGHT, AQUA_PHILOX_ROUNDS, AQUA_PHILOX_UNROLL,
-//               AQUA_STEP_RESEED_QUICK, AQUA_NS_RESEED_QUICK
-//   ablations   AQUA_NO_PAIR_PHILOX, AQUA_NO_ARG_BATCH, AQUA_NS_QUICK=0 / AQUA_QUICK_OTHERS=0 (obstacle look walks the
-//               rows instead of reading the quick table: next-step kernel / the other step kernels)
-//   experiments (results are NOT the product's): AQUA_NS_NOWORK (nobody restarts), AQUA_NS_NOMAIN (re-seeding
-//               blocks alone on a synthetic pending set), AQUA_EXP_NO_DEREF (table header and tick by value),
-//               AQUA_EXP_EXTRA_VALU=n (n extra vector instructions per stepping lane), AQUA_EXP_CLAMP_MINMAX,
-//               AQUA_EXP_NO_EXACT, AQUA_EXP_NO_SECOND, AQUA_EXP_ONE_ROUND
-//   diagnostics AQUA_STAMPS = 1 (phase stamps) | 2 (wavefront start/end only): tools/stamps*.py
+// Build-time switches (diagnostic builds only, aquaticgymenv_amd/build.py build_variant(); never defined in the shipped
+// library): AQUA_STAMPS = 1 | 2 (in-kernel phase stamps + the micro-benchmark kernels of csrc/aqua_tuning.inc, tools/stamps*.py,
+// tools/reseed_bench.py, tools/skeleton.py), AQUA_NS_NOWORK / AQUA_NS_NOMAIN (one role of the next-step kernel alone,
+// tools/sweep_n.sh).  The tuning constants below (tile sizes, group sizes, cache scopes) are plain constants: every
+// alternative that was measured is recorded with its timing in DESIGN.md section 5.3.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -44,15 +36,9 @@ using namespace aqua;
 
 namespace {
 
-#ifndef AQUA_TILE
-#define AQUA_TILE 1024                   // worlds per workgroup tile of the step kernel
-#endif
-constexpr int TILE_WORLDS = AQUA_TILE;   // step kernel: workgroup of TILE_WORLDS / VEC lanes
+constexpr int TILE_WORLDS = 1024;        // step kernel: worlds per workgroup tile (256 / 512: slower)
 constexpr int BLOCK_SMALL = 256;         // reset / fused-rollout kernels
-#ifndef AQUA_RESET_GROUP
-#define AQUA_RESET_GROUP 8               // lanes that share the re-seeding attempts of one finished world
-#endif
-constexpr int RESET_GROUP = AQUA_RESET_GROUP;
+constexpr int RESET_GROUP = 8;           // lanes that share the re-seeding attempts of one finished world (4: 7.3, 16: 7.4 us)
 constexpr int MAX_GRID = 1 << 30;        // step kernel: one workgroup per tile, no grid-stride loop
 
 constexpr size_t AQUA_BLOB_MIN_BYTES = 320;
@@ -75,46 +61,31 @@ struct StepArgs {
     int64_t N, env_offset;
     // rollout only
     int64_t T, action_step_stride, out_step_stride;
-    int64_t reseed_blocks;               // next-step kernel: the first blocks of the grid re-seed (see step_ns_kernel)
+    int64_t reseed_blocks;               // next-step kernel: this many blocks of the grid re-seed (see step_ns_kernel)
     int K, waves, time_limit, auto_reset, random_boat, random_goal;
     float W, sigma;
+    // behind everything the prologues read (tick_housekeeping() fetches these itself, in block 0 only)
+    uint64_t* tick_copy_to;              // nullable: block 0 stores the tick base it read here      } a captured rollout advances
+    uint64_t* tick_bump_to;              // nullable: block 0 stores (tick base it read + tick_bump) } its own tick base (aqua_rollout_f32)
+    uint64_t tick_bump;
 };
 
 // ------------------------------------------------------------------ vector load/store helpers
 // `p` is a wave-uniform row pointer already advanced to the tile, `off` the lane's element offset
 // inside the tile (32-bit), `rem` the number of valid elements from p on.  FULL tiles carry no guards:
 // the loads of a lane are issued back to back as global_load_dword{,x2,x4} v, voffset, s[base].
-// AQUA_LOAD_HINT / AQUA_STORE_HINT (build-time experiments): 0 plain, 1 non-temporal, 2 agent-scope (write-through
-// past the XCD's L2 for stores, L2-bypassing for loads)
-#ifndef AQUA_LOAD_HINT
-#define AQUA_LOAD_HINT 0
-#endif
-#ifndef AQUA_STORE_HINT
-#define AQUA_STORE_HINT 2
-#endif
+// Stores carry agent scope (`global_store ... sc1`): they are written through the XCD's L2 while the kernel runs, so the
+// end-of-kernel release has almost nothing left to write back (-0.3 us per launch; system scope: the same; non-temporal:
+// -0.1; hinted loads: slower -- DESIGN.md section 5.3).
 template <typename T>
 __device__ __forceinline__ T ld1(const T* p)
 {
-#if AQUA_LOAD_HINT == 1
-    return __builtin_nontemporal_load(p);
-#elif AQUA_LOAD_HINT == 2
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
     return *p;
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void st1(T* p, T v)
 {
-#if AQUA_STORE_HINT == 1
-    __builtin_nontemporal_store(v, p);
-#elif AQUA_STORE_HINT == 2
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif AQUA_STORE_HINT == 3
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    *p = v;
-#endif
 }
 
 // uniform base + zero-extended 32-bit BYTE offset: the form the backend turns into `global_load v, voffset, s[base]`
@@ -193,31 +164,12 @@ __device__ __forceinline__ uint64_t spread_bits(uint64_t x)
     return 0;
 }
 
-#if AQUA_OBST_LDS
-#define AQUA_OBST_DECL __shared__ ObstF s_obst[MAX_OBST];
-__device__ __forceinline__ ObstPtr stage_obstacles(ObstF* s_obst, const void* blob, int K)
+// rows are read with scalar loads from the constant address space (they follow the 32-byte header)
+__device__ __forceinline__ ObstPtr obstacle_rows(const void* blob)
 {
-    const float4* src = reinterpret_cast<const float4*>(static_cast<const char*>(blob) + sizeof(ObstHeader));
-    float4* dst = reinterpret_cast<float4*>(s_obst);
-    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-    return s_obst;
-}
-#else
-#define AQUA_OBST_DECL ObstF* s_obst = nullptr;
-__device__ __forceinline__ ObstPtr stage_obstacles(ObstF*, const void* blob, int)
-{
-    // rows are read with scalar loads from the constant address space (they follow the 32-byte header)
     return (ObstPtr)(uintptr_t)(static_cast<const char*>(blob) + sizeof(ObstHeader));
 }
-#endif
 
-#ifndef AQUA_STEP_RESEED_QUICK              // step_kernel<.., SMALL>: re-seed from the quick table (1) or from the rows (0)
-#define AQUA_STEP_RESEED_QUICK 1
-#endif
-#ifndef AQUA_QUICK_OTHERS                   // the other step kernels: QUICK_IF_PRESENT (2) or QUICK_NEVER (0)
-#define AQUA_QUICK_OTHERS QUICK_IF_PRESENT
-#endif
 template <int QUICK = QUICK_NEVER>
 __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
 {
@@ -230,14 +182,9 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
     if (a.obst_blob != nullptr) {        // header fields: uniform scalar loads (the pointer is NULL when K == 0)
         const ObstHeader __attribute__((address_space(4)))* h =
             (const ObstHeader __attribute__((address_space(4)))*)(uintptr_t)a.obst_blob;
-#ifdef AQUA_EXP_NO_DEREF                 // timing experiment only: header by value (BENCH8's), tick by value
-        k.Kc = 4; k.band2 = 3.1e-3f; k.band2_tight = 2.0e-4f;
-        (void)h;
-#else
         k.Kc = h->n_circles;
         k.band2 = h->band2;
         k.band2_tight = h->band2_tight;
-#endif
         // Touch the table's cache lines now (rows 2l - 1 and 2l share line l; row 0 shares the header's): the
         // scalar cache starts every launch cold, and the row loads of the obstacle passes are issued two rows
         // at a time -- each of them would otherwise be a miss of its own, one memory round trip after the other.
@@ -254,11 +201,7 @@ __device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
         // The rows' lines are touched in every case: the second look and the float64 path walk the rows, and although
         // only ~5 % of the launches have a wavefront that goes there, its cold misses then add to the launch
         // (measured without the touches: float64 path 0.15 us per launch on average instead of 0.08).
-#ifndef AQUA_EXP_NO_TOUCH
         k.touch[0] = w[16]; k.touch[1] = w[32]; k.touch[2] = w[48]; k.touch[3] = w[64];
-#else
-        if constexpr (QUICK != QUICK_ALWAYS) { k.touch[0] = w[16]; k.touch[1] = w[32]; k.touch[2] = w[48]; k.touch[3] = w[64]; }
-#endif
     }
     k.obst64 = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.obst_blob) + sizeof(ObstHeader) +
                                                sizeof(ObstF) * a.K);
@@ -360,14 +303,12 @@ __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_
 {
     if constexpr (VEC == 1) {
         const bool odd = (env0 & 1u) != 0;
-#ifndef AQUA_NO_PAIR_PHILOX
         // lanes 2i and 2i + 1 hold the two worlds of one pair whenever the wavefront's first world is even
         // (always, unless the caller's env_offset is odd): the pair then computes its block together
         if (uni((static_cast<uint32_t>(env0) ^ threadIdx.x) & 1u) == 0u) {
             draw_pair(seed, env0 >> 1, tick, stream, 0, odd, w0[0], w1[0]);
             return;
         }
-#endif
         uint32_t r[4];
         draw<SCALAR_KEY>(seed, env0 >> 1, tick, stream, 0, r);
         w0[0] = odd ? r[2] : r[0];
@@ -518,7 +459,7 @@ template <int VEC, int AK, bool SMALL, bool RESTART>
 __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
                                           TileShared& sh)
 {
-    constexpr int QUICK = (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_ALWAYS : QUICK_NEVER;
+    constexpr int QUICK = SMALL ? QUICK_ALWAYS : QUICK_NEVER;
     constexpr int BLOCK = TILE_WORLDS / VEC;
     const int64_t ld = a.ld;
     const int64_t rem = a.N - tile;                      // > 0, uniform
@@ -621,11 +562,11 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const uint32_t i = list[active ? q : 0];
             const uint64_t world = static_cast<uint64_t>(a.env_offset + tile) + i;
             EnvState e;
-            if constexpr (QUICK == QUICK_ALWAYS && AQUA_STEP_RESEED_QUICK)
-                e = reseed_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
-                                                            k.K, k.obst, nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
+            if constexpr (QUICK == QUICK_ALWAYS)
+                e = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                            k.K, k.obst, nullptr, k.quick, k.Kc);
             else
-                e = reseed_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+                e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
                 st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
                 st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -667,22 +608,51 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 // is read through the scalar path (constant address space) like the obstacle table.
 __device__ __forceinline__ uint64_t launch_tick(const StepArgs& a)
 {
-#ifdef AQUA_EXP_NO_DEREF
-    return a.tick;                       // timing experiment only
-#endif
     if (a.tick_base == nullptr) return a.tick;
     return a.tick + *(const uint64_t __attribute__((address_space(4)))*)(uintptr_t)a.tick_base;
+}
+
+// Everything a step kernel's prologue needs from the kernel-argument segment, fetched in ONE batch ahead of the first
+// wait.  Left to itself the compiler sinks some of these loads into the blocks that use them, and each of those is a
+// scalar-memory round trip (0.3-0.5 us) in front of the state loads.
+__device__ __forceinline__ void fetch_args(const StepArgs& a)
+{
+    asm volatile("" ::"s"(a.state), "s"(a.ld), "s"(a.time), "s"(a.action), "s"(a.N), "s"(a.seed), "s"(a.tick),
+                 "s"(a.env_offset), "s"(a.tick_base), "s"(a.obst_blob), "s"(a.noise), "s"(a.reseed_blocks));
+}
+
+// A captured rollout of T >= 2 steps advances its device-resident tick base by itself, without a kernel of its own
+// (a one-thread kernel behind the steps costs the graph 3.9 us per replay: its launch and a dependent load + store):
+// the FIRST step launch copies the base to a scratch word, the LAST one takes its base from that copy and stores
+// base + T where the next replay's launches read it.  No launch reads a word another thread of the same launch writes
+// (the launches of a stream are serialised), so the scalar-path reads of launch_tick() stay coherent.  Called at the top
+// of a kernel's first block only, by one thread.  Its arguments are read from the kernel-argument segment right here,
+// through a laundered pointer: as ordinary uses of `a` the compiler hoists their loads into every block's prologue
+// and, with the SGPR file full, spills them to VGPR lanes there (StepArgs is the kernels' first parameter: offset 0).
+__device__ __forceinline__ void tick_housekeeping()
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        using KernArg = const char __attribute__((address_space(4)))*;
+        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const auto word = [&](size_t off) { return *(const uint64_t __attribute__((address_space(4)))*)(kp + off); };
+        uint64_t* const copy_to = reinterpret_cast<uint64_t*>(word(offsetof(StepArgs, tick_copy_to)));
+        uint64_t* const bump_to = reinterpret_cast<uint64_t*>(word(offsetof(StepArgs, tick_bump_to)));
+        if (copy_to != nullptr || bump_to != nullptr) {
+            const uint64_t base = *reinterpret_cast<const uint64_t*>(word(offsetof(StepArgs, tick_base)));
+            if (copy_to != nullptr) *copy_to = base;
+            if (bump_to != nullptr) *bump_to = base + word(offsetof(StepArgs, tick_bump));
+        }
+    }
 }
 
 template <int VEC, int AK, bool SMALL, bool RESTART>
 __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs a)
 {
-    AQUA_OBST_DECL
     __shared__ TileShared sh;
+    tick_housekeeping();
     if (RESTART && threadIdx.x == 0) sh.count = 0;
-    // (the touches stay: the re-seeding may walk the rows, AQUA_STEP_RESEED_QUICK)
-    const StepConst k = make_const<(SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_IF_PRESENT : QUICK_NEVER>(
-        a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     if (RESTART && a.auto_reset) __syncthreads();
     const uint64_t tick = launch_tick(a);
     step_tile<VEC, AK, SMALL, RESTART>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
@@ -711,31 +681,24 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
 // done_code(T - 1) or the restart_code(T) that replaced it, it skips the world; a done_code(T) written by a
 // stepping wavefront of this launch is not what the scan is looking for.  (Ticks therefore advance by one
 // per step; after a jump in parity a marked world simply waits one more step.)
-#ifndef AQUA_NS_MAIN_WAVES
-#define AQUA_NS_MAIN_WAVES 4
-#endif
-#ifndef AQUA_NS_QUICK                       // 1: stepping blocks read the quick table (tables of up to 8 rows); 0: the rows
-#define AQUA_NS_QUICK 1
-#endif
-#ifndef AQUA_NS_SCAN_ROWS
-#define AQUA_NS_SCAN_ROWS 4
-#endif
-#ifndef AQUA_NS_RESEED_GROUP
-#define AQUA_NS_RESEED_GROUP 8
-#endif
-constexpr int NS_MAIN_WAVES = AQUA_NS_MAIN_WAVES;
+// measured alternatives: 6-wavefront blocks 6.7 us, 8: 6.45, 4: 5.99, 3: 6.3, 2: 7.1; 1024 worlds
+// per re-seeding block 5.99, 512: 6.16, 2048: 6.9; 8 lanes per restarting world 5.99, 4: 7.3, 16: 7.4
+constexpr int NS_MAIN_WAVES = 4;
 constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = NS_TILE;
-constexpr int NS_SCAN_ROWS = AQUA_NS_SCAN_ROWS, NS_SCAN = NS_SCAN_ROWS * NS_BLOCK;      // worlds per re-seeding block
-constexpr int NS_RESEED_GROUP = AQUA_NS_RESEED_GROUP;
+constexpr int NS_SCAN_ROWS = 4, NS_SCAN = NS_SCAN_ROWS * NS_BLOCK;      // worlds per re-seeding block
+constexpr int NS_RESEED_GROUP = 8;
 static_assert(NS_SCAN <= 65536, "list entries are 16-bit offsets");
+static_assert(NS_SCAN % NS_TILE == 0, "a re-seeding block covers whole stepping tiles");
+// batches of at least this many worlds interleave the two roles through the grid (measured: tools/ab.py)
+#ifndef AQUA_NS_INTERLEAVE_MIN
+#define AQUA_NS_INTERLEAVE_MIN (1 << 20)
+#endif
+constexpr int64_t NS_INTERLEAVE_MIN = AQUA_NS_INTERLEAVE_MIN;
 
 __device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static_cast<int32_t>(tick & 1u); }
 __device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
 
-#ifndef AQUA_NS_TABLE_ROWS
-#define AQUA_NS_TABLE_ROWS 8
-#endif
-constexpr int NS_TABLE_ROWS = AQUA_NS_TABLE_ROWS;   // tables of up to this many obstacles are staged in LDS for the re-seeding pass (0: never)
+constexpr int NS_TABLE_ROWS = 8;   // tables of up to this many obstacles are staged in LDS for the re-seeding pass (0: never)
 struct NsReseedShared {
     ObstF rows[NS_TABLE_ROWS > 0 ? NS_TABLE_ROWS : 1];
     uint32_t count[NS_MAIN_WAVES];
@@ -745,12 +708,9 @@ struct NsReseedShared {
 // SMALL_TABLE: the launch has at most NS_TABLE_ROWS obstacles (decided on the host: one kernel per case keeps the
 // code each launch has to fetch short -- the instruction cache starts every launch cold)
 template <bool SMALL_TABLE>
-__device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block, ObstF* s_obst, NsReseedShared& sh)
+__device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block, NsReseedShared& sh)
 {
-#ifndef AQUA_NS_RESEED_PRIO
-#define AQUA_NS_RESEED_PRIO 3
-#endif
-    __builtin_amdgcn_s_setprio(AQUA_NS_RESEED_PRIO);    // the longest chain of the launch: issue first
+    __builtin_amdgcn_s_setprio(3);                      // the longest chain of the launch: issue first
     const int64_t base = block * NS_SCAN;
     const int64_t ld = a.ld, rem = a.N - base;          // > 0
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -766,15 +726,12 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     // Small tables (the usual case) are copied into LDS by the first lanes -- one vector load each, in flight with
     // the time row -- and the obstacle pass of the re-seeding reads them from there after the barrier below,
     // four rows per wait (through the scalar path it waits once per two rows, 200 clocks each).
-#ifndef AQUA_NS_RESEED_QUICK                // 1: small tables are read from the quick table (SGPR operands) instead of LDS
-#define AQUA_NS_RESEED_QUICK (AQUA_RESEED_IMPL == 2)
-#endif
-    constexpr bool reseed_quick = SMALL_TABLE && AQUA_NS_RESEED_QUICK;
-    constexpr bool table_in_regs = SMALL_TABLE && !reseed_quick;
+    // (reading small tables as SGPR operands from the quick table instead loses here: 5.14 vs 5.02 us)
+    constexpr bool table_in_regs = SMALL_TABLE;
     uint32_t table_word = 0;
     if (table_in_regs && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
         table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
-    const StepConst k = make_const<reseed_quick ? QUICK_ALWAYS : QUICK_NEVER>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick = launch_tick(a);
     const int32_t restart = done_code(tick - 1);
     AQUA_RTSTAMP(0);
@@ -818,13 +775,10 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
         const uint64_t env = static_cast<uint64_t>(a.env_offset + base) + i;
         EnvState e;
-        if constexpr (reseed_quick)
-            e = reseed_group<NS_RESEED_GROUP, RESEED_QUICK>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst,
-                                                            nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
-        else if constexpr (SMALL_TABLE)
-            e = reseed_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
+        if constexpr (SMALL_TABLE)
+            e = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
         else
-            e = reseed_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
             st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
             st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
@@ -843,24 +797,38 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
 #ifndef AQUA_NS_WAVES_PER_EU
 #define AQUA_NS_WAVES_PER_EU 6
 #endif
-template <int AK, bool SMALL_TABLE>
+// INTERLEAVE: the grid layout (chosen on the host by batch size, like SMALL_TABLE: one kernel per case keeps the SGPR
+// file of the one-round case -- the benchmarked one -- exactly as tight as it was)
+template <int AK, bool SMALL_TABLE, bool INTERLEAVE>
 __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_NS_WAVES_PER_EU, 8))) void step_ns_kernel(const StepArgs a)
 {
-    AQUA_OBST_DECL
     __shared__ NsReseedShared sh;
-#ifndef AQUA_NO_ARG_BATCH
     // Everything the prologue needs from the kernel-argument segment is fetched in ONE batch, ahead of the
     // first wait: the draws then need no further scalar load (with the tick passed by value they start while
     // the table header, issued behind the state loads, is still on its way).
-    asm volatile("" ::"s"(a.state), "s"(a.ld), "s"(a.time), "s"(a.action), "s"(a.N), "s"(a.seed), "s"(a.tick),
-                 "s"(a.env_offset), "s"(a.tick_base), "s"(a.obst_blob), "s"(a.noise), "s"(a.reseed_blocks));
-#endif
+    fetch_args(a);
     AQUA_RTSTAMP(3);        // wavefront started
-    const bool reseed_role = static_cast<int64_t>(blockIdx.x) < a.reseed_blocks;
-    const int64_t role_index = reseed_role ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) - a.reseed_blocks;
+    tick_housekeeping();
+    // Which role, which tile.  A grid of ONE round of blocks (262 144 worlds fill the 256 CUs exactly once) starts its
+    // re-seeding blocks first -- theirs is the longest chain.  A grid of many rounds would run thousands of re-seeding
+    // blocks (latency-bound, three wavefronts of four busy, no memory traffic) before the first world is stepped, and the
+    // two roles would no longer overlap: there one block in every five re-seeds, next to the four stepping blocks of the
+    // same 1024 worlds (16.7 M worlds: 250-270 -> see DESIGN.md section 5.3).
+    bool reseed_role;
+    int64_t role_index;
+    if constexpr (INTERLEAVE) {
+        constexpr uint32_t PER = NS_SCAN / NS_TILE + 1;
+        const uint32_t group = blockIdx.x / PER, member = blockIdx.x - group * PER;
+        reseed_role = member == 0;
+        role_index = reseed_role ? static_cast<int64_t>(group) : static_cast<int64_t>(group) * (PER - 1) + (member - 1);
+        if (!reseed_role && role_index * NS_TILE >= a.N) return;          // the last group may be short of stepping tiles
+    } else {
+        reseed_role = static_cast<int64_t>(blockIdx.x) < a.reseed_blocks;
+        role_index = reseed_role ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) - a.reseed_blocks;
+    }
     if (reseed_role) {
 #ifndef AQUA_NS_NOWORK                       // (timing experiment: what the re-seeding blocks cost the launch)
-        ns_reseed_block<SMALL_TABLE>(a, role_index, s_obst, sh);
+        ns_reseed_block<SMALL_TABLE>(a, role_index, sh);
 #endif
         return;
     }
@@ -895,7 +863,8 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_N
         avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
         avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
     }
-    const StepConst k = make_const<(SMALL_TABLE && AQUA_NS_QUICK) ? QUICK_ALWAYS : QUICK_NEVER>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;     // tables of up to 8 rows: the quick table (5.22 -> 5.08 us)
+    const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick = launch_tick(a);
     AQUA_RTSTAMP(0);
     // The draws need no loaded value: they run in the shadow of the loads.
@@ -934,11 +903,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_N
     const bool live = valid && !pending;
     AQUA_RTSTAMP(1);
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
-#ifdef AQUA_EXP_NO_EXACT                   // timing experiment only: what the float64 path costs the launch
-    const bool knife = fast_step<false, (SMALL_TABLE && AQUA_NS_QUICK) ? QUICK_ALWAYS : QUICK_NEVER>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live && false;
-#else
-    const bool knife = fast_step<false, (SMALL_TABLE && AQUA_NS_QUICK) ? QUICK_ALWAYS : QUICK_NEVER>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
-#endif
+    const bool knife = fast_step<false, QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
     if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
@@ -946,17 +911,6 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_N
             e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
         }
     }
-#ifdef AQUA_EXP_EXTRA_VALU                  // timing experiment only: this many extra independent-ish VALU operations
-    {
-        float acc0 = rew, acc1 = e.x, acc2 = e.y, acc3 = e.th;
-#pragma unroll
-        for (int z = 0; z < AQUA_EXP_EXTRA_VALU / 4; ++z) {
-            acc0 = fmaf(acc0, 1.0000001f, 1.0e-9f); acc1 = fmaf(acc1, 1.0000001f, 1.0e-9f);
-            acc2 = fmaf(acc2, 1.0000001f, 1.0e-9f); acc3 = fmaf(acc3, 1.0000001f, 1.0e-9f);
-        }
-        if (acc0 + acc1 + acc2 + acc3 == 12345.678f) rew = 0.0f;
-    }
-#endif
     if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
     const bool done = code != 0u;
     // The stores' own copies of the lane offset.  With the loads' o4 the seven row addresses are common
@@ -1047,11 +1001,11 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepA
         const uint32_t owner = sh.list[parity][seg][active ? q - first[seg] : 0];
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
         EnvState f;
-        if constexpr (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER)
-            f = reseed_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
-                                                        k.K, k.obst, nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
+        if constexpr (SMALL)
+            f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+                                                        k.K, k.obst, nullptr, k.quick, k.Kc);
         else
-            f = reseed_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            f = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.result[q];
             r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
@@ -1075,10 +1029,9 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 template <int AK, bool SMALL, int MODE>
 __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs a)     // 4 wavefronts per SIMD: <= 128 VGPRs
 {
-    AQUA_OBST_DECL
     __shared__ RolloutShared sh;
-    constexpr int QUICK = (SMALL && AQUA_QUICK_OTHERS != QUICK_NEVER) ? QUICK_ALWAYS : QUICK_NEVER;
-    const StepConst k = make_const<QUICK == QUICK_ALWAYS ? QUICK_IF_PRESENT : QUICK_NEVER>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    constexpr int QUICK = SMALL ? QUICK_ALWAYS : QUICK_NEVER;
+    const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     // whole blocks iterate together (barriers inside); lanes past N are inert
@@ -1178,6 +1131,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
+    tick_housekeeping();
     const int64_t tile = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL;
     const int64_t ld = a.ld, rem = a.N - tile;
     const int lane = threadIdx.x & 63;
@@ -1276,7 +1230,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32, nullptr, tld, tile + i};
-            const EnvState f = reseed_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
+            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
                                                                           tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
                                                                           nullptr, nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1356,7 +1310,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
         for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
         const int64_t i = base + (active ? sh.list[seg][q - first[seg]] : 0);      // an idle group reads a world that exists
         const WorldTable wt{t32, nullptr, tld, i};
-        const EnvState e = reseed_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
+        const EnvState e = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
                                                                       a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
                                                                       nullptr, 0, &wt);
         if (active && (lane & (RESET_GROUP - 1)) == 0) store(i, e);
@@ -1366,8 +1320,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
 // ------------------------------------------------------------------ masked reset
 __global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, const uint8_t* __restrict__ mask)
 {
-    AQUA_OBST_DECL
-    const ObstPtr obst = stage_obstacles(s_obst, a.obst_blob, a.K);
+    const ObstPtr obst = obstacle_rows(a.obst_blob);
     const uint64_t tick = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL + threadIdx.x; i < N;
@@ -1528,14 +1481,18 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
 {
     StepArgs a = a0;
     a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
-    const int64_t tiles = (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
+    const bool interleave = a.N >= NS_INTERLEAVE_MIN;
+    const int64_t tiles = interleave ? a.reseed_blocks * (NS_SCAN / NS_TILE + 1)
+                                     : (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     if (tiles > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
     const bool small = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;
 #define AQUA_NS_LAUNCH(AK)                                                                           \
     case AK:                                                                                         \
-        if (small) hipLaunchKernelGGL((step_ns_kernel<AK, true>), grid, block, 0, s, a);             \
-        else hipLaunchKernelGGL((step_ns_kernel<AK, false>), grid, block, 0, s, a);                  \
+        if (small && interleave) hipLaunchKernelGGL((step_ns_kernel<AK, true, true>), grid, block, 0, s, a);        \
+        else if (small) hipLaunchKernelGGL((step_ns_kernel<AK, true, false>), grid, block, 0, s, a);                \
+        else if (interleave) hipLaunchKernelGGL((step_ns_kernel<AK, false, true>), grid, block, 0, s, a);           \
+        else hipLaunchKernelGGL((step_ns_kernel<AK, false, false>), grid, block, 0, s, a);                          \
         break;
     switch (kind) {
         AQUA_NS_LAUNCH(AQUA_ACT_U8)
@@ -1695,8 +1652,7 @@ void aqua_discrete_constants(float out[9])
 // one warm Philox draw, executed by a single wavefront that has the SIMD to itself
 __global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, int iters)
 {
-    AQUA_OBST_DECL
-    const StepConst k = make_const<QUICK_IF_PRESENT>(a, stage_obstacles(s_obst, a.obst_blob, a.K));
+    const StepConst k = make_const<QUICK_IF_PRESENT>(a, obstacle_rows(a.obst_blob));
     float acc = 0.0f;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int rep = 0; rep < 2; ++rep) {          // rep 0 warms the instruction and scalar caches
@@ -1704,10 +1660,10 @@ __global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, i
         for (int it = 0; it < iters; ++it) {
             EnvState e;
             if (k.quick != nullptr)
-                e = reseed_group<RESET_GROUP, RESEED_QUICK>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
-                                                            a.tick + it, k.waves, 1, 1, k.K, k.obst, nullptr, k.quick, k.Kc, nullptr, &k.qc0, &k.qr0);
+                e = reset_env_group<RESET_GROUP, RESEED_QUICK>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
+                                                            a.tick + it, k.waves, 1, 1, k.K, k.obst, nullptr, k.quick, k.Kc);
             else
-                e = reseed_group<RESET_GROUP>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
+                e = reset_env_group<RESET_GROUP>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
                                               a.tick + it, k.waves, 1, 1, k.K, k.obst);
             acc += e.x + e.gy;
         }
@@ -1841,7 +1797,8 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
                      float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
                      int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
                      const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
-                     uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, void* stream)
+                     uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, int advance_tick,
+                     void* stream)
 {
     StepArgs a;
     int rc = fill_args(a, p, obst_blob_dev, K, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
@@ -1851,11 +1808,19 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
     if (T < 0 || action_step_stride < 0 || out_step_stride < 0 || done_step_stride < 0)
         return fail(AQUA_E_INVALID, "negative T or stride");
     if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
+    if (advance_tick && tick_base_dev == nullptr) return fail(AQUA_E_INVALID, "advance_tick needs tick_base_dev");
     if (N == 0 || T == 0) return 0;
     a.action_ld = action_ld; a.auto_reset = auto_reset; a.obs_norm = obs_norm;
     const size_t esz = action_elem_bytes(action_kind);
+    uint64_t* const tick_words = const_cast<uint64_t*>(tick_base_dev);       // [0] the base, [1] scratch (advance_tick)
     for (int64_t t = 0; t < T; ++t) {
         a.tick = tick + static_cast<uint64_t>(t);
+        if (advance_tick && T >= 2) {                    // see tick_housekeeping()
+            a.tick_base = (t == T - 1) ? tick_words + 1 : tick_words;
+            a.tick_copy_to = (t == 0) ? tick_words + 1 : nullptr;
+            a.tick_bump_to = (t == T - 1) ? tick_words : nullptr;
+            a.tick_bump = static_cast<uint64_t>(T);
+        }
         a.action = actions ? static_cast<const char*>(actions) + static_cast<size_t>(t * action_step_stride) * esz : nullptr;
         a.reward = reward + t * out_step_stride;
         a.term = term + t * out_step_stride;
@@ -1864,6 +1829,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
         const hipError_t e = launch_step_any(a, action_kind, vec, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "aqua_rollout_f32 launch");
     }
+    if (advance_tick && T == 1) return aqua_tick_advance(tick_words, 1, stream);   // one launch cannot do both halves
     return 0;
 }
 

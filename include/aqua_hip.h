@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 2   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table */
+#define AQUA_ABI_VERSION 3   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
+                                3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
@@ -139,12 +140,17 @@ int aqua_reset_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_
  *                   [2][action_ld]; AQUA_ACT_SAMPLE_*: NULL.  action_step_stride is in ELEMENTS.
  *   reward, term  : per-step outputs, step t writes at + t*out_step_stride elements (0 = overwrite).
  *   done_bits     : likewise with done_step_stride (in uint64 words; 0 = overwrite; NULL = skip).
+ *   advance_tick  : != 0 (needs tick_base_dev, which then points at TWO uint64 words: the base and a scratch word):
+ *                   after the T steps the device-resident base has advanced by T, so that a captured graph of this call
+ *                   draws fresh noise at every replay.  For T >= 2 the first and the last step launch do it themselves
+ *                   (no extra kernel in the graph); for T == 1 it is aqua_tick_advance() behind the step.
  */
 int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
                      float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
                      int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
                      const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
-                     uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, void* stream);
+                     uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, int advance_tick,
+                     void* stream);
 
 /*
  * The same T steps fused into ONE launch: pose, goal, wave and time stay in registers between

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/r02g
+mkdir -p $O
+cd $R
+AQUA_HIP_LIB=$R/aquaticgymenv_amd/lib/variants/libaqua_hip_il0.so python -m pytest tests/test_hip_parity.py -m gpu -x -q > $O/pytest_il0.log 2>&1 || { tail -40 $O/pytest_il0.log; exit 1; }
+tail -2 $O/pytest_il0.log
+python -m pytest tests/test_hip_parity.py -m gpu -x -q > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
+tail -2 $O/pytest_gpu.log
+for n in 16777216 4194304 1048576 524288 393216 262144; do echo "N=$n"; python tools/ab.py --rounds 2 --envs $n --steps 200 il0@2 ilnever@2 2>&1 | grep us/step; done > $O/ab_interleave.txt 2>&1
+cat $O/ab_interleave.txt
