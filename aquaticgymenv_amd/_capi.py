@@ -16,8 +16,8 @@ MAX_OBSTACLES = 64
 SYMBOLS = (
     "aqua_version", "aqua_last_error", "aqua_obstacle_blob_bytes", "aqua_pack_obstacles", "aqua_step_f32",
     "aqua_reset_f32", "aqua_rollout_f32", "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin",
-    "aqua_graph_end", "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width",
-    "aqua_discrete_constants", "aqua_set_vector_width", "aqua_obs_norm_f32",
+    "aqua_graph_end", "aqua_graph_launch", "aqua_graph_destroy",
+    "aqua_discrete_constants", "aqua_obs_norm_f32",
     "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
     "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed",
 )
@@ -73,13 +73,11 @@ def _load():
     lib.aqua_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.aqua_event_destroy.argtypes = [vp]
     lib.aqua_graph_end_timed.argtypes = [vp, ctypes.POINTER(vp), vp, vp]
-    lib.aqua_step_vector_width.argtypes = [vp, i64, vp, vp, vp, ci, i64, vp, i64, vp]
     lib.aqua_discrete_constants.argtypes = [ctypes.POINTER(ctypes.c_float)]
     lib.aqua_discrete_constants.restype = None
-    lib.aqua_set_vector_width.argtypes = [ci]
     for name in ("aqua_pack_obstacles", "aqua_step_f32", "aqua_reset_f32", "aqua_rollout_f32",
                  "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin", "aqua_graph_end",
-                 "aqua_graph_launch", "aqua_graph_destroy", "aqua_step_vector_width", "aqua_set_vector_width",
+                 "aqua_graph_launch", "aqua_graph_destroy",
                  "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
                  "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed"):

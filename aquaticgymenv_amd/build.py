@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "aqua_hip.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "aqua_device.hpp"),
+DEPS = SRC + [os.path.join(HERE, "csrc", "aqua_device.hpp"), os.path.join(HERE, "csrc", "aqua_tuning.inc"),
               os.path.join(os.path.dirname(HERE), "include", "aqua_hip.h")]
 LIB = os.path.join(HERE, "lib", "libaqua_hip.so")
 ARCH = "gfx950"
@@ -60,6 +60,6 @@ def build_variant(name, flags, verbose=False):
 
 if __name__ == "__main__":
     if "--variants" in sys.argv:
-        for name, flags in (("tile256", ["-DAQUA_TILE=256"]), ("lds", ["-DAQUA_OBST_LDS=1"]), ("stamps", ["-DAQUA_STAMPS=1"])):
+        for name, flags in (("stamps", ["-DAQUA_STAMPS=1"]), ("nw", ["-DAQUA_NS_NOWORK"]), ("nm", ["-DAQUA_NS_NOMAIN"])):
             print(build_variant(name, flags, verbose=True))
     print(build_hip(force="--force" in sys.argv, verbose=True))

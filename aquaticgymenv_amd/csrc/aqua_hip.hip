@@ -5,7 +5,7 @@
 //                          split by role -- a few re-seeding blocks at the head of the grid, stepping blocks of
 //                          256 worlds (one per lane) behind them -- with no synchronisation between the two.
 //                          The benchmarked kernel.
-//   step_kernel<VEC, AK>   one launch per batched step, no restart (auto_reset 0) or restart in the same launch
+//   step_kernel<AK>        one launch per batched step, no restart (auto_reset 0) or restart in the same launch
 //                          (auto_reset 1): 1024-world tiles, finished worlds re-seeded after one barrier.
 //   rollout_kernel<AK>     T steps in one launch with the world state held in registers.
 //   reset_kernel           masked reset.   obs_norm_kernel  the DQN's normalised observation after a reset.
@@ -21,7 +21,6 @@
 // alternative that was measured is recorded with its timing in DESIGN.md section 5.3.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -104,15 +103,9 @@ __device__ __forceinline__ void st_at(T* base, uint32_t byte_off, T v)
 template <int VEC, bool FULL, typename T>
 __device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, int64_t rem, T (&v)[VEC])
 {
+    static_assert(VEC == 1, "one world per lane");
     if constexpr (FULL) {
-        if constexpr (VEC == 1) {
-            v[0] = ld1(p + off);
-        } else {
-            struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
-            const Pack q = *reinterpret_cast<const Pack*>(p + off);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) v[j] = q.e[j];
-        }
+        v[0] = ld1(p + off);
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = (static_cast<int64_t>(off) + j < rem) ? p[off + j] : T(0);
@@ -122,46 +115,14 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, 
 template <int VEC, bool FULL, typename T>
 __device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64_t rem, const T (&v)[VEC])
 {
+    static_assert(VEC == 1, "one world per lane");
     if constexpr (FULL) {
-        if constexpr (VEC == 1) {
-            st1(p + off, v[0]);
-        } else {
-            struct alignas(sizeof(T) * VEC) Pack { T e[VEC]; };
-            Pack q;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) q.e[j] = v[j];
-            *reinterpret_cast<Pack*>(p + off) = q;
-        }
+        st1(p + off, v[0]);
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
             if (static_cast<int64_t>(off) + j < rem) p[off + j] = v[j];
     }
-}
-
-// spread the low 64/VEC bits of x so that bit i lands at bit i*VEC (wave-uniform, runs on the SALU)
-template <int VEC>
-__device__ __forceinline__ uint64_t spread_bits(uint64_t x)
-{
-    if constexpr (VEC == 1) return x;
-    if constexpr (VEC == 2) {
-        x &= 0xFFFFFFFFull;
-        x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-        x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-        x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-        x = (x | (x << 2)) & 0x3333333333333333ull;
-        x = (x | (x << 1)) & 0x5555555555555555ull;
-        return x;
-    }
-    if constexpr (VEC == 4) {
-        x &= 0xFFFFull;
-        x = (x | (x << 24)) & 0x000000FF000000FFull;
-        x = (x | (x << 12)) & 0x000F000F000F000Full;
-        x = (x | (x << 6)) & 0x0303030303030303ull;
-        x = (x | (x << 3)) & 0x1111111111111111ull;
-        return x;
-    }
-    return 0;
 }
 
 // rows are read with scalar loads from the constant address space (they follow the 32-byte header)
@@ -254,7 +215,7 @@ __device__ __forceinline__ int sample_discrete(uint32_t r) { return static_cast<
 __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u_01(r), 0.2f); }
 
 // ------------------------------------------------------------------ one launch per step
-// Workgroup = TILE_WORLDS / VEC lanes, tile = TILE_WORLDS consecutive worlds.  Worlds that finish are
+// Workgroup = TILE_WORLDS lanes, tile = TILE_WORLDS consecutive worlds, one per lane.  Worlds that finish are
 // not re-seeded by their own lane (that would be 1-2 active lanes per wavefront, in every wavefront,
 // looping over rejection attempts): their tile-local indices are appended to a list in LDS and, after
 // one barrier, groups of RESET_GROUP lanes re-seed them densely (reset_env_group) and write the fresh
@@ -301,27 +262,18 @@ template <int VEC, bool SCALAR_KEY = true>
 __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream,
                                            uint32_t (&w0)[VEC], uint32_t (&w1)[VEC])
 {
-    if constexpr (VEC == 1) {
-        const bool odd = (env0 & 1u) != 0;
-        // lanes 2i and 2i + 1 hold the two worlds of one pair whenever the wavefront's first world is even
-        // (always, unless the caller's env_offset is odd): the pair then computes its block together
-        if (uni((static_cast<uint32_t>(env0) ^ threadIdx.x) & 1u) == 0u) {
-            draw_pair(seed, env0 >> 1, tick, stream, 0, odd, w0[0], w1[0]);
-            return;
-        }
-        uint32_t r[4];
-        draw<SCALAR_KEY>(seed, env0 >> 1, tick, stream, 0, r);
-        w0[0] = odd ? r[2] : r[0];
-        w1[0] = odd ? r[3] : r[1];
-    } else {
-#pragma unroll
-        for (int p = 0; p < VEC / 2; ++p) {             // env0 is even for VEC >= 2 (checked on the host)
-            uint32_t r[4];
-            draw<SCALAR_KEY>(seed, (env0 >> 1) + p, tick, stream, 0, r);
-            w0[2 * p] = r[0]; w1[2 * p] = r[1];
-            w0[2 * p + 1] = r[2]; w1[2 * p + 1] = r[3];
-        }
+    static_assert(VEC == 1, "one world per lane");
+    const bool odd = (env0 & 1u) != 0;
+    // lanes 2i and 2i + 1 hold the two worlds of one pair whenever the wavefront's first world is even
+    // (always, unless the caller's env_offset is odd): the pair then computes its block together
+    if (uni((static_cast<uint32_t>(env0) ^ threadIdx.x) & 1u) == 0u) {
+        draw_pair(seed, env0 >> 1, tick, stream, 0, odd, w0[0], w1[0]);
+        return;
     }
+    uint32_t r[4];
+    draw<SCALAR_KEY>(seed, env0 >> 1, tick, stream, 0, r);
+    w0[0] = odd ? r[2] : r[0];
+    w1[0] = odd ? r[3] : r[1];
 }
 
 // Optional fused epilogue: the observation as main/impl/utils.py:15-33 (AquaStateNormalizer) hands it to the DQN --
@@ -363,19 +315,11 @@ __device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, u
         store_row<VEC, false>(a.reward + tile, off, rem, rew);
         store_row<VEC, false>(a.term + tile, off, rem, code);
     }
+    static_assert(VEC == 1, "one world per lane: the wavefront's ballot IS its done word");
     if (a.done_bits != nullptr) {
-        uint64_t mine = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const uint64_t b = __ballot((done_mask >> j) & 1u);
-#pragma unroll
-            for (int wq = 0; wq < VEC; ++wq) {
-                const uint64_t piece = spread_bits<VEC>(b >> (wq * (64 / VEC))) << j;
-                if (lane == wq) mine |= piece;
-            }
-        }
-        const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u) * VEC) / 64 + lane;
-        if (lane < VEC && word < ((a.N + 63) >> 6)) a.done_bits[word] = mine;
+        const uint64_t b = __ballot(done_mask & 1u);
+        const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u)) / 64;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
     }
 }
 
@@ -455,10 +399,15 @@ __device__ __forceinline__ void fold_actions(const int64_t (&araw)[VEC], int (&a
 // SMALL_TABLE): the obstacle look and the re-seeding read it, and nothing walks the rows outside the rare paths.
 // RESTART == false: the launch never restarts a world (auto_reset 0, the reference's own step()): no list, no
 // barrier, no re-seeding code in the kernel.  RESTART == true serves both (the run-time a.auto_reset decides).
-template <int VEC, int AK, bool SMALL, bool RESTART>
+template <int AK, bool SMALL, bool RESTART>
 __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
                                           TileShared& sh)
 {
+    // One world per lane.  Two and four worlds per lane (16-byte row accesses) were built and measured at every batch
+    // size up to 16.7 M worlds and never won (262 144: 20 vs 37 us in round 1; 16.7 M without restarts: 177 / 183 /
+    // 184 us for 1 / 2 / 4, profiles/r02/ab_16m_vec.txt): the helpers below keep their width parameter, the kernels no
+    // longer have one.
+    constexpr int VEC = 1;
     constexpr int QUICK = SMALL ? QUICK_ALWAYS : QUICK_NEVER;
     constexpr int BLOCK = TILE_WORLDS / VEC;
     const int64_t ld = a.ld;
@@ -646,8 +595,8 @@ __device__ __forceinline__ void tick_housekeeping()
     }
 }
 
-template <int VEC, int AK, bool SMALL, bool RESTART>
-__global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs a)
+template <int AK, bool SMALL, bool RESTART>
+__global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const StepArgs a)
 {
     __shared__ TileShared sh;
     tick_housekeeping();
@@ -655,7 +604,7 @@ __global__ __launch_bounds__(TILE_WORLDS / VEC) void step_kernel(const StepArgs 
     const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     if (RESTART && a.auto_reset) __syncthreads();
     const uint64_t tick = launch_tick(a);
-    step_tile<VEC, AK, SMALL, RESTART>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
+    step_tile<AK, SMALL, RESTART>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
 // ------------------------------------------------------------------ one launch per step, next-step restart
@@ -689,9 +638,11 @@ constexpr int NS_SCAN_ROWS = 4, NS_SCAN = NS_SCAN_ROWS * NS_BLOCK;      // world
 constexpr int NS_RESEED_GROUP = 8;
 static_assert(NS_SCAN <= 65536, "list entries are 16-bit offsets");
 static_assert(NS_SCAN % NS_TILE == 0, "a re-seeding block covers whole stepping tiles");
-// batches of at least this many worlds interleave the two roles through the grid (measured: tools/ab.py)
+// batches of at least this many worlds interleave the two roles through the grid.  Measured per step, interleaved vs
+// head-of-grid (profiles/r02/ab_interleave.txt): 16.7 M 215 vs 288 us, 8.4 M 98 vs 106, 6.3 M 90 vs 86, 4.2 M 63 vs 61,
+// 1 M 14.6 vs 14.3, 262 144 5.60 vs 5.55
 #ifndef AQUA_NS_INTERLEAVE_MIN
-#define AQUA_NS_INTERLEAVE_MIN (1 << 20)
+#define AQUA_NS_INTERLEAVE_MIN (1 << 23)
 #endif
 constexpr int64_t NS_INTERLEAVE_MIN = AQUA_NS_INTERLEAVE_MIN;
 
@@ -1368,7 +1319,6 @@ __global__ __launch_bounds__(BLOCK_SMALL) void obs_norm_kernel(const float* __re
 
 // ------------------------------------------------------------------ host side
 thread_local char g_err[512] = "";
-std::atomic<int> g_vec_override{0};
 
 int fail(int code, const char* fmt, ...)
 {
@@ -1427,41 +1377,18 @@ size_t action_elem_bytes(int kind)
     }
 }
 
-int pick_vec(const float* state, int64_t ld, const int32_t* time, const float* reward, const void* action,
-             int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld, const uint8_t* term, int64_t N,
-             int64_t env_offset)
-{
-    if (env_offset & 1) return 1;          // noise pairs (world >> 1) must not straddle lanes
-    int want = g_vec_override.load();
-    if (want == 0) want = 1;            // measured fastest at every batch size (profiles/)
-    for (int v = want; v > 1; v >>= 1) {
-        bool ok = aligned(state, 4 * v) && aligned(time, 4 * v) && aligned(reward, 4 * v) && (ld % v == 0) &&
-                  aligned(term, v);
-        if (action_kind == AQUA_ACT_U8) ok = ok && aligned(action, v);
-        if (action_kind == AQUA_ACT_I32) ok = ok && aligned(action, 4 * v);
-        if (action_kind == AQUA_ACT_I64) ok = ok && aligned(action, 8 * v);
-        if (action_kind == AQUA_ACT_F32X2) ok = ok && aligned(action, 4 * v) && (action_ld % v == 0);
-        if (noise != nullptr) ok = ok && aligned(noise, 4 * v) && (noise_ld % v == 0);
-        if (ok) return v;
-    }
-    return 1;
-}
-
-template <int VEC>
 hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
 {
-    const int64_t items = (a.N + VEC - 1) / VEC;
     if ((a.N + TILE_WORLDS - 1) / TILE_WORLDS > MAX_GRID) return hipErrorInvalidValue;
-    const dim3 grid(grid_for(items, TILE_WORLDS / VEC, MAX_GRID)), block(TILE_WORLDS / VEC);
+    const dim3 grid(grid_for(a.N, TILE_WORLDS, MAX_GRID)), block(TILE_WORLDS);
     const bool small = a.K > 0 && a.K <= QUICK_MAX;
-    // (the no-restart specialisation exists for one world per lane, the width every batch size runs fastest at)
-    const bool plain = VEC == 1 && a.auto_reset == 0;
+    const bool plain = a.auto_reset == 0;               // no restart: no list, no barrier, no re-seeding code in the kernel
 #define AQUA_STEP_LAUNCH(AK)                                                                                     \
     case AK:                                                                                                     \
-        if (plain && small) hipLaunchKernelGGL((step_kernel<VEC, AK, true, VEC != 1>), grid, block, 0, s, a);    \
-        else if (plain) hipLaunchKernelGGL((step_kernel<VEC, AK, false, VEC != 1>), grid, block, 0, s, a);       \
-        else if (small) hipLaunchKernelGGL((step_kernel<VEC, AK, true, true>), grid, block, 0, s, a);            \
-        else hipLaunchKernelGGL((step_kernel<VEC, AK, false, true>), grid, block, 0, s, a);                      \
+        if (plain && small) hipLaunchKernelGGL((step_kernel<AK, true, false>), grid, block, 0, s, a);            \
+        else if (plain) hipLaunchKernelGGL((step_kernel<AK, false, false>), grid, block, 0, s, a);               \
+        else if (small) hipLaunchKernelGGL((step_kernel<AK, true, true>), grid, block, 0, s, a);                 \
+        else hipLaunchKernelGGL((step_kernel<AK, false, true>), grid, block, 0, s, a);                           \
         break;
     switch (kind) {
         AQUA_STEP_LAUNCH(AQUA_ACT_U8)
@@ -1508,12 +1435,10 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_step_any(const StepArgs& a, int kind, int vec, hipStream_t s)
+hipError_t launch_step_any(const StepArgs& a, int kind, hipStream_t s)
 {
     if (a.auto_reset == AQUA_RESET_NEXT_STEP) return launch_step_ns(a, kind, s);
-    if (vec == 4) return launch_step<4>(a, kind, s);
-    if (vec == 2) return launch_step<2>(a, kind, s);
-    return launch_step<1>(a, kind, s);
+    return launch_step(a, kind, s);
 }
 
 int check_step_buffers(int64_t N, const void* action, int action_kind, int64_t action_ld, const float* noise,
@@ -1633,13 +1558,6 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
     return 0;
 }
 
-int aqua_step_vector_width(const float* state, int64_t ld, const int32_t* time, const float* reward,
-                           const void* action, int action_kind, int64_t action_ld, const float* noise,
-                           int64_t noise_ld, const uint8_t* term)
-{
-    return pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, INT64_MAX, 0);
-}
-
 void aqua_discrete_constants(float out[9])
 {
     const float v[9] = {ACT_H_TURN, -ACT_H_TURN, ACT_H_LINE, ACT_W_TURN, -ACT_W_TURN, ACT_W_LINE,
@@ -1648,115 +1566,8 @@ void aqua_discrete_constants(float out[9])
 }
 
 #if AQUA_STAMPS
-// micro-benchmark (diagnostic build only): cycles of one warm call of the re-seeding group routine and of
-// one warm Philox draw, executed by a single wavefront that has the SIMD to itself
-__global__ void reseed_bench_kernel(const StepArgs a, unsigned long long* out, int iters)
-{
-    const StepConst k = make_const<QUICK_IF_PRESENT>(a, obstacle_rows(a.obst_blob));
-    float acc = 0.0f;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    for (int rep = 0; rep < 2; ++rep) {          // rep 0 warms the instruction and scalar caches
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-        for (int it = 0; it < iters; ++it) {
-            EnvState e;
-            if (k.quick != nullptr)
-                e = reset_env_group<RESET_GROUP, RESEED_QUICK>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
-                                                            a.tick + it, k.waves, 1, 1, k.K, k.obst, nullptr, k.quick, k.Kc);
-            else
-                e = reset_env_group<RESET_GROUP>(true, a.seed, static_cast<uint64_t>(threadIdx.x / RESET_GROUP + 8 * it),
-                                              a.tick + it, k.waves, 1, 1, k.K, k.obst);
-            acc += e.x + e.gy;
-        }
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-        for (int it = 0; it < iters; ++it) {
-            uint32_t r[4];
-            draw(a.seed, threadIdx.x + 64ull * it, a.tick, STREAM_PLACE, 0, r);
-            acc += u_01(r[0] ^ r[3]);
-        }
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
-        for (int it = 0; it < iters; ++it) {
-            uint32_t w0, w1;
-            draw_pair(a.seed, (threadIdx.x >> 1) + 64ull * it, a.tick, STREAM_PLACE, 0, (threadIdx.x & 1) != 0, w0, w1);
-            acc += u_01(w0 ^ w1);
-        }
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3)::"memory");
-    }
-    // exact path: first (cold instruction cache) call vs later calls, one wavefront
-    unsigned long long e0, e1, e2, e3;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0)::"memory");
-    ExactOut o = exact_step(50.0f + acc * 0.0f, 50.0f, 0.3f, 20.0f, 80.0f, 0.01f, 0.02f, 5, exact_motion_discrete(threadIdx.x % 3), k.K,
-                            k.obst64, k.obst, k.band2, k.time_limit);
-    acc += o.x;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory");
-    o = exact_step(51.0f + acc * 0.0f, 50.0f, 0.3f, 20.0f, 80.0f, 0.01f, 0.02f, 5, exact_motion_discrete(threadIdx.x % 3), k.K, k.obst64,
-                   k.obst, k.band2, k.time_limit);
-    acc += o.x;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e2)::"memory");
-    o = exact_step(52.0f + acc * 0.0f, 50.0f, 0.3f, 20.0f, 80.0f, 0.01f, 0.02f, 5, exact_motion_discrete(threadIdx.x % 3), k.K, k.obst64,
-                   k.obst, k.band2, k.time_limit);
-    acc += o.x;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e3)::"memory");
-    if (threadIdx.x == 0) { out[0] = (t1 - t0) / iters; out[1] = (t2 - t1) / iters; out[6] = (t3 - t2) / iters; out[3] = e1 - e0; out[4] = e2 - e1; out[5] = e3 - e2; }
-    if (acc == 12345.678f) out[2] = 1;
-}
-
-int aqua_debug_reseed_bench(const AquaParams* p, const void* blob, int K, unsigned long long* out_dev, void* stream)
-{
-    StepArgs a;
-    float dummy_state = 0.0f;
-    int32_t dummy_time = 0;
-    const int rc = fill_args(a, p, blob, K, 1, 0, &dummy_state, 1, &dummy_time, 12345, 7, nullptr);
-    if (rc) return rc;
-    hipLaunchKernelGGL(reseed_bench_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a, out_dev, 200);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "reseed bench");
-}
-
-// Launch skeletons for tools/skeleton.py: what a launch of the step's shape costs with (kind 0) an empty
-// body, (kind 1) the step's memory traffic only (8 rows + 1 byte in, 6 rows + 1 float + 1 byte out per world),
-// (kind 2) kind 1 with `spin` dependent FMAs per lane between the loads and the stores.
-__global__ void __launch_bounds__(512) skeleton_kernel(int kind, float* buf, int64_t ld, int64_t n, int spin)
-{
-    if (kind == 0) return;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = buf[j * ld + i];
-    const uint8_t act = reinterpret_cast<const uint8_t*>(buf + 8 * ld)[i];
-    float acc = v[0] + act;
-    for (int s = 0; s < spin; ++s) acc = fmaf(acc, 1.0000001f, v[1]);
-    v[0] = acc;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) st1(buf + j * ld + i, v[j] + 1.0f);
-#pragma unroll
-    for (int j = 5; j < 8; ++j) st1(buf + j * ld + i, v[j] + 1.0f);
-    st1(buf + 9 * ld + i, v[3] + v[4]);
-    st1(reinterpret_cast<uint8_t*>(buf + 10 * ld) + i, static_cast<uint8_t>(act + 1));
-}
-
-int aqua_debug_skeleton(int kind, int block, float* buf, int64_t ld, int64_t n, int spin, void* stream)
-{
-    if (block < 64 || block > 512) return fail(AQUA_E_INVALID, "block must be 64..512");
-    const int64_t grid = (n + block - 1) / block;
-    hipLaunchKernelGGL(skeleton_kernel, dim3(static_cast<unsigned>(grid)), dim3(block), 0, static_cast<hipStream_t>(stream),
-                       kind, buf, ld, n, spin);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : hip_fail(e, "skeleton");
-}
-
-int aqua_debug_set_stamps(unsigned long long* dev_ptr)
-{
-    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_ptr, sizeof(dev_ptr));
-    return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyToSymbol(g_stamps)");
-}
+#include "aqua_tuning.inc"               // diagnostic builds only
 #endif
-
-int aqua_set_vector_width(int width)
-{
-    if (!(width == 0 || width == 1 || width == 2 || width == 4)) return fail(AQUA_E_INVALID, "width must be 0, 1, 2 or 4");
-    return g_vec_override.exchange(width);
-}
 
 int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
                   float* state, int64_t ld, int32_t* time, const void* action, int action_kind,
@@ -1775,8 +1586,7 @@ int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t
     a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
     a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = auto_reset;
     if (obs_norm != nullptr && !aligned(obs_norm, 4)) return fail(AQUA_E_ALIGN, "obs_norm must be 4-byte aligned");
-    const int vec = pick_vec(state, ld, time, reward, action, action_kind, action_ld, noise, noise_ld, term, N, env_offset);
-    const hipError_t e = launch_step_any(a, action_kind, vec, static_cast<hipStream_t>(stream));
+    const hipError_t e = launch_step_any(a, action_kind, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_step_f32 launch");
 }
 
@@ -1825,8 +1635,7 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
         a.reward = reward + t * out_step_stride;
         a.term = term + t * out_step_stride;
         a.done_bits = done_bits ? done_bits + t * done_step_stride : nullptr;
-        const int vec = pick_vec(state, ld, time, a.reward, a.action, action_kind, action_ld, nullptr, 0, a.term, N, env_offset);
-        const hipError_t e = launch_step_any(a, action_kind, vec, static_cast<hipStream_t>(stream));
+        const hipError_t e = launch_step_any(a, action_kind, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "aqua_rollout_f32 launch");
     }
     if (advance_tick && T == 1) return aqua_tick_advance(tick_words, 1, stream);   // one launch cannot do both halves

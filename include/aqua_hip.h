@@ -22,8 +22,8 @@
  * State layout (struct of arrays, float32): `state` points at 7 rows of `ld` floats:
  *      row 0 x, 1 y, 2 theta, 3 goal_x, 4 goal_y, 5 wave_x, 6 wave_y        (ld >= N)
  * Rows 0..4 ARE the observation of aqua.py:213 (obs[:, k] = state[k*ld + i]); nothing is copied.
- * `time` is int32[N] (aqua.py:82,141).  Vectorised (16-byte) access is used when `state`,
- * `time`, `reward` are 16-byte aligned and ld % 4 == 0; otherwise a scalar kernel runs.
+ * `time` is int32[N] (aqua.py:82,141).  Rows are read and written one 4-byte element per lane (coalesced 256-byte
+ * wavefront accesses); 4-byte alignment is all the kernels need.
  */
 #ifndef AQUA_HIP_H
 #define AQUA_HIP_H
@@ -233,16 +233,9 @@ int aqua_graph_end_timed(void* stream, AquaGraph** out, AquaEvent* start, AquaEv
 int aqua_event_elapsed_ms(AquaEvent* start, AquaEvent* stop, float* ms);
 int aqua_event_destroy(AquaEvent* e);
 
-/* Introspection for tests and bench: which kernel variant a call with these arguments would run. */
-int aqua_step_vector_width(const float* state, int64_t ld, const int32_t* time, const float* reward,
-                           const void* action, int action_kind, int64_t action_ld, const float* noise,
-                           int64_t noise_ld, const uint8_t* term);
 /* the float32 constants the kernels use for the three discrete actions (aqua.py:33-42 folded through
  * aqua.py:159-170): out = h[3] (w/2), w[3], chord[3]; for tests. */
 void aqua_discrete_constants(float out[9]);
-/* override the automatic choice (0 = auto, 1, 2 or 4 worlds per lane); returns the previous value. */
-int aqua_set_vector_width(int width);
-
 #ifdef __cplusplus
 }
 #endif

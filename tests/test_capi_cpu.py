@@ -174,8 +174,15 @@ def test_argument_validation_without_touching_a_device(capi):
                              addr, None, None, 0, None) == -2    # misaligned state
     assert lib.aqua_step_f32(ctypes.byref(p), None, 0, 8, 0, addr, 8, addr, addr, 0, 0, None, 0, 1, 0, None, addr, addr,
                              None, None, 3, None) == -1    # auto_reset outside 0..2
-    assert lib.aqua_set_vector_width(3) == -1
-    assert lib.aqua_set_vector_width(0) in (0, 1, 2, 4)
+    vp = ctypes.c_void_p
+    rollout = [ctypes.byref(p), None, 0, 8, 0, addr, 8, addr, 4, addr, 0, 0, 0, 1, 0, None, addr, addr, 0, None, 0, None]
+    assert lib.aqua_rollout_f32(*rollout, 3, 0, None) == -1             # auto_reset outside 0..2
+    assert lib.aqua_rollout_f32(*rollout, 0, 1, None) == -1             # advance_tick without a tick base
+    assert b"advance_tick" in lib.aqua_last_error()
+    fused = [ctypes.byref(p), None, 0, 8, 0, addr, 8, addr, 4, addr, 0, 0, 0, 1, 0, None, addr, addr, 0]
+    assert lib.aqua_rollout_fused_f32(*fused, 3, None) == -1            # auto_reset outside 0..2
+    assert lib.aqua_event_record(None, None) == -1 and lib.aqua_event_destroy(None) == 0
+    del vp
     with pytest.raises(ValueError):
         capi.check(-1, "x")
     with pytest.raises(capi.AquaError):

@@ -36,13 +36,6 @@ def golden():
     return StepGolden()
 
 
-@pytest.fixture(params=[1, 2, 4], ids=["vec1", "vec2", "vec4"])
-def vec(request, capi):
-    capi.lib.aqua_set_vector_width(request.param)
-    yield request.param
-    capi.lib.aqua_set_vector_width(0)
-
-
 def _make(torch, n, cfg_or_rows, continuous=False, waves=1, seed=1234, auto_reset=False, env_offset=0, **kw):
     from aquaticgymenv_amd.batched import BatchedAqua
     return BatchedAqua(n, obstacles=cfg_or_rows, waves=bool(waves), continuous=continuous, seed=seed,
@@ -57,7 +50,7 @@ def _host_state(env):
 # (1) golden vectors from the reference
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ci", range(8))
-def test_golden_rows(torch, golden, vec, ci):
+def test_golden_rows(torch, golden, ci):
     cfg = golden.cfg(ci)
     rows = golden.rows(ci)
     n = rows["term"].shape[0]
@@ -212,7 +205,7 @@ def test_decisions_at_the_thresholds_at_scale(torch, oracle, obst, mode):
 
 @pytest.mark.parametrize("n,continuous,obst", [(4096, False, "none"), (262144, False, "bench8"), (262144, True, "bench8"),
                                                (1000, True, "default5"), (65, False, "difficult6")])
-def test_step_matches_oracle_philox(torch, oracle, vec, n, continuous, obst):
+def test_step_matches_oracle_philox(torch, oracle, n, continuous, obst):
     from aquaticgymenv_amd import presets
     rows = {"none": presets.NONE, "bench8": presets.BENCH8, "default5": presets.DEFAULT5,
             "difficult6": presets.DIFFICULT6}[obst]
@@ -627,7 +620,7 @@ def test_timed_graph_brackets_its_launches(torch):
 # layout / shapes
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 1000, 4099])
-def test_ragged_sizes_and_done_bits(torch, oracle, vec, n):
+def test_ragged_sizes_and_done_bits(torch, oracle, n):
     from aquaticgymenv_amd import presets
     env = _make(torch, n, presets.DIFFICULT6, seed=n)
     env.reset()

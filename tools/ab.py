@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of library variants on ONE GPU box (each measurement in a fresh process).
-usage: python tools/ab.py [--rounds 3] [--envs N] name1 name2 ...   (name = variant under lib/variants or 'default')"""
+usage: python tools/ab.py [--rounds 3] [--envs N] name1 name2 ...   (name = variant under lib/variants or 'default', name@mode = restart mode 0 | 1 | 2)"""
 import argparse
 import os
 import subprocess
@@ -21,7 +21,6 @@ sys.path.insert(0, %r)
 import torch
 from aquaticgymenv_amd import presets, _capi
 from aquaticgymenv_amd.batched import BatchedAqua
-_capi.lib.aqua_set_vector_width(int(os.environ.get("AQUA_VEC", "0")))
 n, steps = %d, %d
 env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=int(os.environ.get("AQUA_RESET_MODE", "1")), device="cuda:0")
 env.reset()
@@ -44,9 +43,7 @@ res = {n: [] for n in args.names}
 for r in range(args.rounds):
     for name in args.names:
         env = dict(os.environ)
-        name, _, vec = name.partition(":")
         name, _, mode = name.partition("@")
-        env["AQUA_VEC"] = vec or "0"
         env["AQUA_RESET_MODE"] = mode or "1"
         if name != "default":
             env["AQUA_HIP_LIB"] = os.path.join(ROOT, "aquaticgymenv_amd", "lib", "variants", "libaqua_hip_%s.so" % name)
@@ -54,7 +51,7 @@ for r in range(args.rounds):
             env.pop("AQUA_HIP_LIB", None)
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
         try:
-            res[name + ("@" + mode if mode else "") + (":" + vec if vec else "")].append(float(out.stdout.strip().splitlines()[-1]))
+            res[name + ("@" + mode if mode else "")].append(float(out.stdout.strip().splitlines()[-1]))
         except Exception:
             print("FAILED", name, out.stderr[-500:])
 for name in args.names:
