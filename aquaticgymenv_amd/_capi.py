@@ -19,7 +19,7 @@ SYMBOLS = (
     "aqua_graph_end", "aqua_graph_launch", "aqua_graph_destroy",
     "aqua_discrete_constants", "aqua_obs_norm_f32",
     "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
-    "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed",
+    "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
 )
 
 
@@ -63,6 +63,8 @@ def _load():
     lib.aqua_pack_tables.argtypes = [vp, ci, i64, i64, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.aqua_step_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, vp, ci, i64, vp, i64,
                                          u64, u64, vp, vp, vp, vp, vp, ci, vp]
+    lib.aqua_rollout_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64,
+                                            u64, u64, vp, vp, vp, i64, vp, i64, vp, ci, ci, vp]
     lib.aqua_reset_tables_f32.argtypes = [pp, vp, ci, i64, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_graph_begin.argtypes = [vp]
     lib.aqua_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
@@ -80,7 +82,7 @@ def _load():
                  "aqua_graph_launch", "aqua_graph_destroy",
                  "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
-                 "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed"):
+                 "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32"):
         getattr(lib, name).restype = ci
     if lib.aqua_version() != ABI_VERSION:
         raise ImportError("libaqua_hip.so ABI %d != binding %d: rebuild" % (lib.aqua_version(), ABI_VERSION))

@@ -123,9 +123,6 @@ class BatchedAqua(object):
             self._tab32 = self._tab64 = None
             self._r_max = 0.0
             if self.per_world:
-                if self.auto_reset == 2:
-                    raise ValueError("per-world obstacle tables: auto_reset is False or 'same_step'; 'next_step' is the "
-                                     "shared-table kernel's")
                 t32 = np.zeros((self.K, 6, self.ld), dtype=np.float32)
                 t64 = np.zeros((self.K, 5, self.ld), dtype=np.float64)
                 r_max = ctypes.c_float(0.0)
@@ -300,8 +297,6 @@ class BatchedAqua(object):
         return self.obs, self.reward[:n], self.term[:n]
 
     def _rollout_args(self, steps, actions, soa_ld):
-        if self.per_world:
-            raise NotImplementedError("per-world obstacle tables are stepped one launch at a time (step())")
         torch = self.torch
         n = self.num_envs
         if actions is None or isinstance(actions, str):
@@ -350,8 +345,14 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
+        if fused and self.per_world:
+            raise NotImplementedError("the fused rollout kernel keeps ONE obstacle table in SGPRs: per-world tables run as "
+                                      "one launch per step (rollout(fused=False) / capture_rollout())")
         with torch.cuda.device(self.device):
-            if fused:
+            if self.per_world:
+                _capi.check(self._rollout_tables(steps, aptr, kind, ald, astride, self._tick, None, reward, term, ostride,
+                                                 done, dstride, 0, self._stream()), "aqua_rollout_tables_f32")
+            elif fused:
                 _capi.check(lib.aqua_rollout_fused_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
                                                        self.env_offset, self.state.data_ptr(), self.ld,
                                                        self.time.data_ptr(), steps, aptr, kind, ald, astride, self.seed,
@@ -367,6 +368,14 @@ class BatchedAqua(object):
         self._tick += steps
         return reward, term
 
+    def _rollout_tables(self, steps, aptr, kind, ald, astride, tick, tick_base, reward, term, ostride, done, dstride, advance, s):
+        return _capi.lib.aqua_rollout_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),
+                                                 self.K, self.ld, self._r_max, self.num_envs, self.env_offset,
+                                                 self.state.data_ptr(), self.ld, self.time.data_ptr(), steps, aptr, kind, ald,
+                                                 astride, self.seed, tick, tick_base, reward.data_ptr(), term.data_ptr(),
+                                                 ostride, done.data_ptr(), dstride, self._norm_ptr(), int(self.auto_reset),
+                                                 advance, s)
+
     def capture_rollout(self, steps, actions=None, fused=False, keep_all=False, done_history=None, timing=False):
         """Capture `steps` batched steps into a HIP graph.  Noise stays fresh across replays: the
         kernels add a device-resident tick base that the graph's last node advances by `steps`.
@@ -376,6 +385,9 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
+        if fused and self.per_world:
+            raise NotImplementedError("the fused rollout kernel keeps ONE obstacle table in SGPRs: per-world tables are "
+                                      "captured as one launch per step (fused=False)")
         self._sync_device_tick()
         cap = torch.cuda.Stream(device=self.device)
         cap.wait_stream(torch.cuda.current_stream(self.device))
@@ -390,7 +402,9 @@ class BatchedAqua(object):
             _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
             try:
                 tb = self._tick_dev.data_ptr()
-                if fused:
+                if self.per_world:
+                    rc = self._rollout_tables(steps, aptr, kind, ald, astride, 0, tb, reward, term, ostride, done, dstride, 1, s)
+                elif fused:
                     rc = lib.aqua_rollout_fused_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
                                                     self.env_offset, self.state.data_ptr(), self.ld,
                                                     self.time.data_ptr(), steps, aptr, kind, ald, astride, self.seed, 0,
@@ -415,47 +429,6 @@ class BatchedAqua(object):
         g = RolloutGraph(self, handle, steps, reward, term, events)
         g._actions = actions          # keep the action buffer alive as long as the graph
         g.done_history = done if dstride else None
-        return g
-
-    def capture_steps_per_world(self, steps, actions):
-        """Per-world obstacle tables: capture `steps` step launches (restart per self.auto_reset: none, or same-step
-        inside the launch) into a HIP graph.  actions: uint8 [steps][ld] (discrete).
-        Ticks come from the device-resident base like capture_rollout()'s, so replays draw fresh noise."""
-        if not self.per_world or self.continuous:
-            raise NotImplementedError("capture_steps_per_world: discrete worlds with per-world obstacle tables")
-        torch = self.torch
-        if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[0] < steps or actions.shape[1] < self.num_envs \
-                or actions.stride(1) != 1:
-            raise ValueError("actions must be uint8 [steps][>=N]")
-        lib = _capi.lib
-        self._sync_device_tick()
-        cap = torch.cuda.Stream(device=self.device)
-        cap.wait_stream(torch.cuda.current_stream(self.device))
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device), torch.cuda.stream(cap):
-            s = self._stream()
-            _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
-            rc = 0
-            try:
-                tb = self._tick_dev.data_ptr()
-                for i in range(steps):
-                    rc = lib.aqua_step_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),
-                                                  self.K, self.ld, self._r_max, self.num_envs, self.env_offset,
-                                                  self.state.data_ptr(), self.ld, self.time.data_ptr(),
-                                                  actions[i].data_ptr(), _capi.ACT_U8, 0, None, 0, self.seed, i, tb,
-                                                  self.reward.data_ptr(), self.term.data_ptr(), self.done_bits.data_ptr(),
-                                                  self._norm_ptr(), int(self.auto_reset), s)
-                    if rc:
-                        break
-                if rc == 0:
-                    rc = lib.aqua_tick_advance(tb, steps, s)
-            finally:
-                rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
-            _capi.check(rc, "capture per-world steps")
-            _capi.check(rc_end, "aqua_graph_end")
-        torch.cuda.current_stream(self.device).wait_stream(cap)
-        g = RolloutGraph(self, handle, steps, self.reward, self.term)
-        g._actions = actions
         return g
 
     # ------------------------------------------------------------------ helpers

@@ -642,9 +642,12 @@ static_assert(NS_SCAN % NS_TILE == 0, "a re-seeding block covers whole stepping 
 // head-of-grid (profiles/r02/ab_interleave.txt): 16.7 M 215 vs 288 us, 8.4 M 98 vs 106, 6.3 M 90 vs 86, 4.2 M 63 vs 61,
 // 1 M 14.6 vs 14.3, 262 144 5.60 vs 5.55
 #ifndef AQUA_NS_INTERLEAVE_MIN
-#define AQUA_NS_INTERLEAVE_MIN (1 << 23)
+#define AQUA_NS_INTERLEAVE_MIN (1 << 19)
 #endif
 constexpr int64_t NS_INTERLEAVE_MIN = AQUA_NS_INTERLEAVE_MIN;
+#ifndef AQUA_NS_XCD_GROUPS
+#define AQUA_NS_XCD_GROUPS 1
+#endif
 
 __device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static_cast<int32_t>(tick & 1u); }
 __device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
@@ -748,6 +751,39 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
 #ifndef AQUA_NS_WAVES_PER_EU
 #define AQUA_NS_WAVES_PER_EU 6
 #endif
+// Which role, which tile (next-step kernels).  A grid of ONE round of blocks (262 144 worlds fill the 256 CUs exactly
+// once) starts its re-seeding blocks first -- theirs is the longest chain.  A grid of many rounds would run thousands of
+// re-seeding blocks (latency-bound, three wavefronts of four busy, no memory traffic) before the first world is stepped,
+// and the two roles would no longer overlap: there one block in every five re-seeds, next to the four stepping blocks of
+// the same 1024 worlds (16.7 M worlds: 288 -> 195-215 us per step).  Returns false for the spare
+// blocks of a rounded-up grid.
+template <bool INTERLEAVE>
+__device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, int64_t& role_index)
+{
+    if constexpr (INTERLEAVE) {
+        // Group g = the re-seeding block and the four stepping blocks of worlds [1024 g, 1024 g + 1024).  Blocks are dealt
+        // round-robin over the 8 XCDs (blocks b and b + 8 share one: observed, relied on for speed only), so the five
+        // members of a group are blocks x + 8 (5 q + m), m = 0..4, of group 8 q + x: one XCD, one L2 -- the time row the
+        // re-seeding block scans is the one its stepping neighbours read.
+        constexpr uint32_t PER = NS_SCAN / NS_TILE + 1;
+#if AQUA_NS_XCD_GROUPS
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const uint32_t q = j / PER, member = j - q * PER;
+        const uint32_t group = q * 8u + x;
+#else
+        const uint32_t group = blockIdx.x / PER, member = blockIdx.x - group * PER;
+#endif
+        reseed_role = member == 0;
+        role_index = reseed_role ? static_cast<int64_t>(group) : static_cast<int64_t>(group) * (PER - 1) + (member - 1);
+        if (static_cast<int64_t>(group) >= a.reseed_blocks) return false;    // the grid is rounded up to whole sets of 8 groups
+        if (!reseed_role && role_index * NS_TILE >= a.N) return false;       // the last group may be short of stepping tiles
+    } else {
+        reseed_role = static_cast<int64_t>(blockIdx.x) < a.reseed_blocks;
+        role_index = reseed_role ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) - a.reseed_blocks;
+    }
+    return true;
+}
+
 // INTERLEAVE: the grid layout (chosen on the host by batch size, like SMALL_TABLE: one kernel per case keeps the SGPR
 // file of the one-round case -- the benchmarked one -- exactly as tight as it was)
 template <int AK, bool SMALL_TABLE, bool INTERLEAVE>
@@ -760,23 +796,9 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_N
     fetch_args(a);
     AQUA_RTSTAMP(3);        // wavefront started
     tick_housekeeping();
-    // Which role, which tile.  A grid of ONE round of blocks (262 144 worlds fill the 256 CUs exactly once) starts its
-    // re-seeding blocks first -- theirs is the longest chain.  A grid of many rounds would run thousands of re-seeding
-    // blocks (latency-bound, three wavefronts of four busy, no memory traffic) before the first world is stepped, and the
-    // two roles would no longer overlap: there one block in every five re-seeds, next to the four stepping blocks of the
-    // same 1024 worlds (16.7 M worlds: 250-270 -> see DESIGN.md section 5.3).
     bool reseed_role;
     int64_t role_index;
-    if constexpr (INTERLEAVE) {
-        constexpr uint32_t PER = NS_SCAN / NS_TILE + 1;
-        const uint32_t group = blockIdx.x / PER, member = blockIdx.x - group * PER;
-        reseed_role = member == 0;
-        role_index = reseed_role ? static_cast<int64_t>(group) : static_cast<int64_t>(group) * (PER - 1) + (member - 1);
-        if (!reseed_role && role_index * NS_TILE >= a.N) return;          // the last group may be short of stepping tiles
-    } else {
-        reseed_role = static_cast<int64_t>(blockIdx.x) < a.reseed_blocks;
-        role_index = reseed_role ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) - a.reseed_blocks;
-    }
+    if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
     if (reseed_role) {
 #ifndef AQUA_NS_NOWORK                       // (timing experiment: what the re-seeding blocks cost the launch)
         ns_reseed_block<SMALL_TABLE>(a, role_index, sh);
@@ -1073,17 +1095,22 @@ __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs 
 // RESTART (auto_reset 1, same-step): worlds that finish are published on an LDS list (one private segment per
 // wavefront) and, after ONE barrier, re-seeded eight lanes per world against their own tables (draws of this tick,
 // like step_kernel); the owning lane keeps its reward / term stores and skips its state stores.
+constexpr int RESET_SCAN_ROWS = 4, RESET_SCAN = RESET_SCAN_ROWS * BLOCK_SMALL, RESET_DENSE = RESET_SCAN / 8;
+struct ResetShared {
+    uint32_t count[BLOCK_SMALL / 64];
+    uint16_t list[BLOCK_SMALL / 64][RESET_SCAN_ROWS * 64];
+};
 struct TablesShared {
     uint32_t count[BLOCK_SMALL / 64];
     uint8_t list[BLOCK_SMALL / 64][64];
 };
-template <int AK, bool RESTART>
-__global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
-                                                                  const double* __restrict__ t64, int64_t tld,
-                                                                  float band2, float band2_tight)
+// MODE: AQUA_RESET_NONE, AQUA_RESET_SAME_STEP (restart inside the launch, below), AQUA_RESET_NEXT_STEP (the stepping
+// role of step_tables_ns_kernel: worlds carrying a restart marker do not step, as in step_ns_kernel).
+template <int AK, int MODE>
+__device__ __forceinline__ void tables_step_block(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
+                                                  int64_t tld, float band2, float band2_tight, int64_t tile)
 {
-    tick_housekeeping();
-    const int64_t tile = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL;
+    constexpr bool RESTART = MODE == AQUA_RESET_SAME_STEP;
     const int64_t ld = a.ld, rem = a.N - tile;
     const int lane = threadIdx.x & 63;
     float* const row0 = a.state + tile;
@@ -1096,7 +1123,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
     float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
     int64_t araw[1] = {2};
     int aidx[1] = {2};
-    const int32_t t0 = ld_at(trow, o4);
+    const int32_t tin = ld_at(trow, o4);
     x[0] = ld_at(row0 + 0 * ld, o4); y[0] = ld_at(row0 + 1 * ld, o4); th[0] = ld_at(row0 + 2 * ld, o4);
     gx[0] = ld_at(row0 + 3 * ld, o4); gy[0] = ld_at(row0 + 4 * ld, o4);
     wx[0] = ld_at(row0 + 5 * ld, o4); wy[0] = ld_at(row0 + 6 * ld, o4);
@@ -1129,13 +1156,16 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
     }
     fold_actions<1, AK>(araw, aidx);
     if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
+    // next-step restart: restarted last tick -> steps from time 0; any other marker -> the world does not step
+    const int32_t t0 = (MODE == AQUA_RESET_NEXT_STEP && tin == restart_code(tick - 1)) ? 0 : tin;
+    const bool live = valid && !(MODE == AQUA_RESET_NEXT_STEP && t0 < 0);
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
     EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
     const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
     const WorldTable wt{t32, t64, tld, tile + o};
     float rew;
     uint32_t code;
-    const bool knife = fast_step<true>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt) && valid;
+    const bool knife = fast_step<true>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt) && live;
     if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step_world(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.band2,
@@ -1143,16 +1173,17 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
             e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
         }
     }
-    const bool done = valid && code != 0u;
+    if (!live) { rew = 0.0f; code = 0u; }                 // a restarting (or padding) world reports reward 0, term 0
+    const bool done = code != 0u;
     if (valid) {
         st_at(a.reward + tile, o4, rew);
         st_at(a.term + tile, o, static_cast<uint8_t>(code));
-        if (!(RESTART && done)) {                         // a finished world's fresh state is written by its group below
-            st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
-            st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
-            st_at(trow, o4, e.t);
-            write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
-        }
+    }
+    if (live && !(RESTART && done)) {                     // same-step: a finished world's fresh state is written by its group below
+        st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
+        st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
+        st_at(trow, o4, (MODE == AQUA_RESET_NEXT_STEP && done) ? done_code(tick) : e.t);
+        write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
     }
     const uint64_t done_ballot = __ballot(done);
     if (a.done_bits != nullptr) {
@@ -1195,16 +1226,94 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
     }
 }
 
+template <int AK, bool RESTART>
+__global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
+                                                                  const double* __restrict__ t64, int64_t tld,
+                                                                  float band2, float band2_tight)
+{
+    tick_housekeeping();
+    tables_step_block<AK, RESTART ? AQUA_RESET_SAME_STEP : AQUA_RESET_NONE>(a, t32, t64, tld, band2, band2_tight,
+                                                                             static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
+}
+
+// Next-step restart with per-world tables: step_ns_kernel's launch split by role (same markers in the time row, same
+// grid layouts), the stepping blocks being tables_step_block<AK, NEXT_STEP> and the re-seeding blocks re-seeding each
+// finished world eight lanes per world against ITS OWN table (the masked reset's groups, with the tick of this step).
+// Nothing of the re-seeding chain -- four dependent global round trips for the rows of a group's table -- is on the
+// step's path any more, which is what the same-step form pays for (17.5 us per step at 262 144 worlds, 8 rows).
+static_assert(NS_TILE == BLOCK_SMALL, "the stepping role of the per-world next-step kernel is one tables_step_block per block");
+template <int AK, bool INTERLEAVE>
+__global__ __launch_bounds__(NS_BLOCK) void step_tables_ns_kernel(const StepArgs a, const float* __restrict__ t32,
+                                                                  const double* __restrict__ t64, int64_t tld,
+                                                                  float band2, float band2_tight)
+{
+    __shared__ ResetShared sh;
+    tick_housekeeping();
+    bool reseed_role;
+    int64_t role_index;
+    if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
+    if (!reseed_role) {
+        tables_step_block<AK, AQUA_RESET_NEXT_STEP>(a, t32, t64, tld, band2, band2_tight, role_index * NS_TILE);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    static_assert(RESET_SCAN == NS_SCAN && RESET_SCAN_ROWS == NS_SCAN_ROWS, "one scan shape for both re-seeding kernels");
+    constexpr int WAVES = NS_BLOCK / 64;
+    const int64_t base = role_index * NS_SCAN, ld = a.ld, rem = a.N - base;        // rem > 0
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t last = static_cast<uint32_t>(rem < NS_SCAN ? rem - 1 : NS_SCAN - 1);
+    int32_t tw[NS_SCAN_ROWS];
+#pragma unroll
+    for (int j = 0; j < NS_SCAN_ROWS; ++j) {              // the loads first
+        const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
+        tw[j] = ld1(a.time + base + (i < last ? i : last));
+    }
+    const uint64_t tick = launch_tick(a);
+    const int32_t restart = done_code(tick - 1);
+    uint32_t n_mine = 0;
+#pragma unroll
+    for (int j = 0; j < NS_SCAN_ROWS; ++j) {              // wavefront-private compaction: ballot + prefix count
+        const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
+        const bool p = static_cast<int64_t>(i) < rem && tw[j] == restart;
+        const uint64_t m = __ballot(p);
+        if (p) sh.list[wave][n_mine + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = static_cast<uint16_t>(i);
+        n_mine += static_cast<uint32_t>(__builtin_popcountll(m));
+    }
+    if (lane == 0) sh.count[wave] = n_mine;
+    __syncthreads();
+    uint32_t first[WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.count[w];
+    const uint32_t n = uni(first[WAVES]);
+    constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+    for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n; qb += PER_BLOCK) {
+        const uint32_t q = qb + (lane / RESET_GROUP);
+        const bool active = q < n;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+        const int64_t i = base + (active ? sh.list[seg][q - first[seg]] : 0);      // an idle group reads a world that exists
+        const WorldTable own{t32, nullptr, tld, i};
+        const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
+                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
+                                                                      nullptr, 0, &own);
+        if (active && (lane & (RESET_GROUP - 1)) == 0) {
+            st1(a.state + 0 * ld + i, f.x); st1(a.state + 1 * ld + i, f.y); st1(a.state + 2 * ld + i, f.th);
+            st1(a.state + 3 * ld + i, f.gx); st1(a.state + 4 * ld + i, f.gy);
+            st1(a.state + 5 * ld + i, f.wx); st1(a.state + 6 * ld + i, f.wy);
+            st1(a.time + i, restart_code(tick));
+            write_norm(a, i, f.x, f.y, f.th, f.gx, f.gy);
+        }
+    }
+}
+
 // Masked reset against per-world tables.  A block reads the mask of RESET_SCAN worlds and compacts the selected ones
 // into an LDS list (ballot + prefix count per wavefront, one barrier).  Few selected (the restart after a step:
 // ~2 % of the worlds): they are re-seeded eight lanes per world like everywhere else -- with one world per lane,
 // three wavefronts of four would each loop over rejection attempts for one or two live lanes.  Many selected (a
 // whole-batch reset): one world per lane, the serial specification.  Bit-identical either way.
-constexpr int RESET_SCAN_ROWS = 4, RESET_SCAN = RESET_SCAN_ROWS * BLOCK_SMALL, RESET_DENSE = RESET_SCAN / 8;
-struct ResetShared {
-    uint32_t count[BLOCK_SMALL / 64];
-    uint16_t list[BLOCK_SMALL / 64][RESET_SCAN_ROWS * 64];
-};
 __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArgs a, const uint8_t* __restrict__ mask,
                                                                    const float* __restrict__ t32, int64_t tld)
 {
@@ -1409,7 +1518,7 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     StepArgs a = a0;
     a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
     const bool interleave = a.N >= NS_INTERLEAVE_MIN;
-    const int64_t tiles = interleave ? a.reseed_blocks * (NS_SCAN / NS_TILE + 1)
+    const int64_t tiles = interleave ? (a.reseed_blocks + 7) / 8 * 8 * (NS_SCAN / NS_TILE + 1)
                                      : (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     if (tiles > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
@@ -1744,38 +1853,34 @@ int fill_table_args(StepArgs& a, const AquaParams* p, const float* tab32, int K,
 }
 }  // namespace
 
-int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
-                         float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time,
-                         const void* action, int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld,
-                         uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
-                         uint64_t* done_bits, float* obs_norm, int auto_reset, void* stream)
+namespace {
+struct TableArgs {
+    const float* t32;
+    const double* t64;
+    int64_t tld;
+    float band2, band2_tight;
+};
+
+hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, hipStream_t s)
 {
-    StepArgs a;
-    if (auto_reset != AQUA_RESET_NONE && auto_reset != AQUA_RESET_SAME_STEP)
-        return fail(AQUA_E_INVALID, "per-world tables: auto_reset must be 0 (none) or 1 (same step), got %d", auto_reset);
-    int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
-    if (rc) return rc;
-    if (tab64_dev == nullptr || !aligned(tab64_dev, 8)) return fail(AQUA_E_INVALID, "tab64 is NULL or not 8-byte aligned");
-    if (!(r_max >= 2.5f)) return fail(AQUA_E_INVALID, "r_max=%g: use the value aqua_pack_tables returned", (double)r_max);
-    rc = check_step_buffers(N, action, action_kind, action_ld, noise, noise_ld, reward, term);
-    if (rc) return rc;
-    if (N == 0) return 0;
-    a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
-    a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = auto_reset;
-    const double R = static_cast<double>(r_max);
-    const float band2 = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND));
-    const float band2_tight = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) +
-                                                 4.0 * 1.1920929e-7 * R * R);
-    const int64_t blocks = (N + BLOCK_SMALL - 1) / BLOCK_SMALL;
-    if (blocks > MAX_GRID) return fail(AQUA_E_INVALID, "N too large for one launch");
+    StepArgs a = a0;
+    const bool ns = a.auto_reset == AQUA_RESET_NEXT_STEP;
+    const bool interleave = ns && a.N >= NS_INTERLEAVE_MIN;
+    int64_t blocks = (a.N + BLOCK_SMALL - 1) / BLOCK_SMALL;
+    if (ns) {
+        a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
+        blocks = interleave ? (a.reseed_blocks + 7) / 8 * 8 * (NS_SCAN / NS_TILE + 1) : blocks + a.reseed_blocks;
+    }
+    if (blocks > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
-    hipStream_t s = static_cast<hipStream_t>(stream);
 #define AQUA_TAB_LAUNCH(AK)                                                                                                          \
     case AK:                                                                                                                          \
-        if (auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, true>), grid, block, 0, s, a, tab32_dev, tab64_dev, tld, band2, band2_tight); \
-        else hipLaunchKernelGGL((step_tables_kernel<AK, false>), grid, block, 0, s, a, tab32_dev, tab64_dev, tld, band2, band2_tight); \
+        if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, true>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else hipLaunchKernelGGL((step_tables_kernel<AK, false>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
         break;
-    switch (action_kind) {
+    switch (kind) {
         AQUA_TAB_LAUNCH(AQUA_ACT_U8)
         AQUA_TAB_LAUNCH(AQUA_ACT_I32)
         AQUA_TAB_LAUNCH(AQUA_ACT_I64)
@@ -1783,11 +1888,88 @@ int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const doub
         AQUA_TAB_LAUNCH(AQUA_ACT_SAMPLE_D)
         AQUA_TAB_LAUNCH(AQUA_ACT_SAMPLE_C)
         AQUA_TAB_LAUNCH(AQUA_ACT_BEARING)
-        default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
+        default: return hipErrorInvalidValue;
     }
 #undef AQUA_TAB_LAUNCH
-    const hipError_t e = hipGetLastError();
+    return hipGetLastError();
+}
+
+int check_tables(TableArgs& t, const float* tab32_dev, const double* tab64_dev, int64_t tld, float r_max)
+{
+    if (tab64_dev == nullptr || !aligned(tab64_dev, 8)) return fail(AQUA_E_INVALID, "tab64 is NULL or not 8-byte aligned");
+    if (!(r_max >= 2.5f)) return fail(AQUA_E_INVALID, "r_max=%g: use the value aqua_pack_tables returned", (double)r_max);
+    const double R = static_cast<double>(r_max);
+    t.t32 = tab32_dev; t.t64 = tab64_dev; t.tld = tld;
+    t.band2 = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND));
+    t.band2_tight = static_cast<float>(2.5 * (R + static_cast<double>(BAND)) * static_cast<double>(BAND_TIGHT) +
+                                       4.0 * 1.1920929e-7 * R * R);
+    return 0;
+}
+}  // namespace
+
+int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                         float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time,
+                         const void* action, int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld,
+                         uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                         uint64_t* done_bits, float* obs_norm, int auto_reset, void* stream)
+{
+    StepArgs a;
+    if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
+    int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
+    if (rc) return rc;
+    TableArgs t;
+    rc = check_tables(t, tab32_dev, tab64_dev, tld, r_max);
+    if (rc) return rc;
+    rc = check_step_buffers(N, action, action_kind, action_ld, noise, noise_ld, reward, term);
+    if (rc) return rc;
+    if (done_bits != nullptr && !aligned(done_bits, 8)) return fail(AQUA_E_ALIGN, "done_bits must be 8-byte aligned");
+    if (N == 0) return 0;
+    a.action = action; a.action_ld = action_ld; a.noise = noise; a.noise_ld = noise_ld;
+    a.reward = reward; a.term = term; a.done_bits = done_bits; a.obs_norm = obs_norm; a.auto_reset = auto_reset;
+    const hipError_t e = launch_step_tables(a, t, action_kind, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_step_tables_f32 launch");
+}
+
+int aqua_rollout_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                            float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time, int64_t T,
+                            const void* actions, int action_kind, int64_t action_ld, int64_t action_step_stride,
+                            uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                            int64_t out_step_stride, uint64_t* done_bits, int64_t done_step_stride, float* obs_norm,
+                            int auto_reset, int advance_tick, void* stream)
+{
+    StepArgs a;
+    if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
+    int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
+    if (rc) return rc;
+    TableArgs t;
+    rc = check_tables(t, tab32_dev, tab64_dev, tld, r_max);
+    if (rc) return rc;
+    rc = check_step_buffers(N, actions, action_kind, action_ld, nullptr, 0, reward, term);
+    if (rc) return rc;
+    if (T < 0 || action_step_stride < 0 || out_step_stride < 0 || done_step_stride < 0)
+        return fail(AQUA_E_INVALID, "negative T or stride");
+    if (advance_tick && tick_base_dev == nullptr) return fail(AQUA_E_INVALID, "advance_tick needs tick_base_dev");
+    if (N == 0 || T == 0) return 0;
+    a.action_ld = action_ld; a.auto_reset = auto_reset; a.obs_norm = obs_norm;
+    const size_t esz = action_elem_bytes(action_kind);
+    uint64_t* const tick_words = const_cast<uint64_t*>(tick_base_dev);
+    for (int64_t s = 0; s < T; ++s) {
+        a.tick = tick + static_cast<uint64_t>(s);
+        if (advance_tick && T >= 2) {                    // see tick_housekeeping()
+            a.tick_base = (s == T - 1) ? tick_words + 1 : tick_words;
+            a.tick_copy_to = (s == 0) ? tick_words + 1 : nullptr;
+            a.tick_bump_to = (s == T - 1) ? tick_words : nullptr;
+            a.tick_bump = static_cast<uint64_t>(T);
+        }
+        a.action = actions ? static_cast<const char*>(actions) + static_cast<size_t>(s * action_step_stride) * esz : nullptr;
+        a.reward = reward + s * out_step_stride;
+        a.term = term + s * out_step_stride;
+        a.done_bits = done_bits ? done_bits + s * done_step_stride : nullptr;
+        const hipError_t e = launch_step_tables(a, t, action_kind, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "aqua_rollout_tables_f32 launch");
+    }
+    if (advance_tick && T == 1) return aqua_tick_advance(tick_words, 1, stream);
+    return 0;
 }
 
 int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, int64_t tld, int64_t N, int64_t env_offset,

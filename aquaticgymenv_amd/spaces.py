@@ -1,7 +1,8 @@
 """Minimal stand-ins for the two gym space classes the reference exposes on its env
 (gym_aqua/envs/aqua.py:30,43,46,52): callers read .shape/.low/.high/.n and call .sample()/.contains()
 (main/impl/dqn.py:99-100, main/impl/utils.py:19-21, main/testing/test_random.py:20).
-If gym or gymnasium is importable the real classes are used instead (see make_box / make_discrete)."""
+The facade always uses these (also when gym is importable): they accept everything the reference's callers do with
+the real classes, and the env works the same with or without gym installed."""
 import numpy as np
 
 

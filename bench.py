@@ -443,33 +443,35 @@ def committed_traffic(n, args):
 
 
 def per_world_tables(torch, np, presets, BatchedAqua, n, dev):
-    """separate line: every world with its own obstacle list (BENCH8, each obstacle moved by up to +-3 units per
-    world), same-step restart inside the step launch, HIP graph of 100 steps.  Algorithmic bytes per
-    world-step: 62 + 24 per obstacle row read (6 float32 per row)."""
+    """separate lines: every world with its own obstacle list (BENCH8, each obstacle moved by up to +-3 units per
+    world), HIP graph of 100 steps, both restart modes.  Algorithmic bytes per world-step: 62 + 24 per obstacle row
+    read (6 float32 per row)."""
     rng = np.random.RandomState(7)
     tables = np.repeat(presets.BENCH8[None], n, axis=0).astype(np.float64)
     tables[:, :, 0:2] += rng.uniform(-3, 3, (n, 8, 2))
-    env = BatchedAqua(n, obstacles=tables, seed=0, auto_reset="same_step", device=dev)
-    env.reset()
-    g = torch.Generator(device=dev).manual_seed(99)
-    actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=g, dtype=torch.int64).to(torch.uint8)
-    graph = env.capture_steps_per_world(CHUNK, actions)
-    for _ in range(3):
-        graph.launch()
-    torch.cuda.synchronize()
-    reps = 10
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        graph.launch()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * CHUNK)
     a_bytes = A_DISCRETE + 24 * 8
-    return {"env_steps_per_s": n / us * 1e6, "us_per_step": us, "launches_per_step": 1,
-            "algorithmic_bytes_per_world_step": a_bytes, "achieved_GBps": a_bytes * n / us / 1e3,
-            "frac_of_8TBps": a_bytes * n / us / 1e3 / HBM_PEAK_GBPS,
-            "note": "per-world obstacle tables [K][6][N] float32, finished worlds restarted inside the step launch (same-step)"}
+    out = {"algorithmic_bytes_per_world_step": a_bytes, "layout": "per-world obstacle tables [K][6][N] float32"}
+    for mode in ("next_step", "same_step"):
+        env = BatchedAqua(n, obstacles=tables, seed=0, auto_reset=mode, device=dev)
+        env.reset()
+        g = torch.Generator(device=dev).manual_seed(99)
+        actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=g, dtype=torch.int64).to(torch.uint8)
+        graph = env.capture_rollout(CHUNK, actions=actions, keep_all=False)
+        for _ in range(3):
+            graph.launch()
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            graph.launch()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (reps * CHUNK)
+        out[mode] = {"env_steps_per_s": n / us * 1e6, "us_per_step": us, "launches_per_step": 1,
+                     "achieved_GBps": a_bytes * n / us / 1e3, "frac_of_8TBps": a_bytes * n / us / 1e3 / HBM_PEAK_GBPS}
+        del graph, env
+    return out
 
 
 def extras(env, torch, n, a_bytes):

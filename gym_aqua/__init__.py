@@ -2,8 +2,8 @@
 by the batched HIP implementation in aquaticgymenv_amd.
 
 Six ids: Aqua{,Continuous}Env-v0 (no obstacles unless asked), -v1 (the default five obstacles),
--v2 (the six "difficult" obstacles).  They are registered with gym or gymnasium when one of them is
-importable; `gym_aqua.make(id, **kwargs)` works either way.
+-v2 (the six "difficult" obstacles).  They are registered with classic `gym` when it is importable (the reference's
+target; the classes speak its reset()/step() protocol, not gymnasium's); `gym_aqua.make(id, **kwargs)` works either way.
 """
 from aquaticgymenv_amd import presets
 
@@ -17,21 +17,27 @@ difficult_obstacles = _VERSIONS["v2"]["obstacles"]
 
 
 def _register_with(module):
-    from_registration = getattr(module.envs.registration, "register")
+    """register the six ids with a gym-like module (anything with envs.registration.register(id=, entry_point=, kwargs=)),
+    as the reference's gym_aqua/__init__.py:4-41 does.  An id that is registered already (the package imported twice)
+    keeps its first registration; any other failure is the caller's to see."""
+    register = module.envs.registration.register
     for env_id, (entry, kwargs) in REGISTRY.items():
         try:
-            from_registration(id=env_id, entry_point=entry, kwargs=kwargs)
-        except Exception:          # already registered (re-import) -> keep the first registration
-            pass
+            register(id=env_id, entry_point=entry, kwargs=kwargs)
+        except Exception as exc:
+            if "register" not in str(exc).lower():      # gym.error.Error("Cannot re-register id: ...")
+                raise
 
 
-for _name in ("gym", "gymnasium"):
-    try:
-        _mod = __import__(_name)
-        __import__(_name + ".envs.registration")
-        _register_with(_mod)
-    except Exception:
-        pass
+# Classic `gym` only: the classes implement the reference's API (gym 0.17: reset() -> obs, step() -> 4-tuple, no
+# seed/options keywords), which gymnasium's make() wrappers and env checker reject.
+try:
+    import gym as _gym_module
+    import gym.envs.registration  # noqa: F401
+except Exception:                  # gym is optional (absent from the build image): gym_aqua.make() works without it
+    _gym_module = None
+if _gym_module is not None:
+    _register_with(_gym_module)
 
 
 def make(env_id, **kwargs):

@@ -23,16 +23,12 @@ import numpy as np
 from aquaticgymenv_amd import presets, spaces
 from aquaticgymenv_amd.batched import BatchedAqua, TIME_LIMIT
 
-try:                                   # gym / gymnasium are optional (absent from the build image)
-    import gym as _gym
+try:                                   # classic gym is optional (absent from the build image); gymnasium's Env base is
+    import gym as _gym                 # not used: these classes speak the reference's gym 0.17 protocol
     _EnvBase = _gym.Env
 except Exception:                      # pragma: no cover - depends on the environment
-    try:
-        import gymnasium as _gym
-        _EnvBase = _gym.Env
-    except Exception:
-        _gym = None
-        _EnvBase = object
+    _gym = None
+    _EnvBase = object
 
 INFO_KEYS = ("Termination.collided", "Termination.time", "Termination.success")
 

@@ -174,10 +174,11 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
  *   tab64  float64 [K][5][tld]  the rows as given, for the float64 knife-edge path
  * and returns the largest collision radius of the batch in *r_max (sizes the knife-edge bands).
  *
- * aqua_step_tables_f32 / aqua_reset_tables_f32 are aqua_step_f32 (auto_reset = AQUA_RESET_NONE or AQUA_RESET_SAME_STEP:
- * a finished world is re-initialised in the launch that finished it, with the draws of that tick, as aqua_step_f32
- * does it) / aqua_reset_f32 with these tables; all other arguments mean what they mean there.  Results for a batch whose worlds all hold the
- * same list are bit-identical to the shared-table calls.  Algorithmic bytes per world-step: 62 + 24 K (discrete).
+ * aqua_step_tables_f32 / aqua_rollout_tables_f32 / aqua_reset_tables_f32 are aqua_step_f32 / aqua_rollout_f32 /
+ * aqua_reset_f32 with these tables: every restart mode (AQUA_RESET_NEXT_STEP is the same role-split launch with the same
+ * markers in time[]), every action kind, and all other arguments mean what they mean there.  Results for a batch whose
+ * worlds all hold the same list are bit-identical to the shared-table calls.  Algorithmic bytes per world-step:
+ * 62 + 24 K (discrete).
  */
 int aqua_pack_tables(const double* rows, int K, int64_t N, int64_t tld, float* tab32_host, double* tab64_host,
                      float* r_max);
@@ -186,6 +187,12 @@ int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const doub
                          const void* action, int action_kind, int64_t action_ld, const float* noise, int64_t noise_ld,
                          uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
                          uint64_t* done_bits, float* obs_norm, int auto_reset, void* stream);
+int aqua_rollout_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                            float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time, int64_t T,
+                            const void* actions, int action_kind, int64_t action_ld, int64_t action_step_stride,
+                            uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                            int64_t out_step_stride, uint64_t* done_bits, int64_t done_step_stride, float* obs_norm,
+                            int auto_reset, int advance_tick, void* stream);
 int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, int64_t tld, int64_t N, int64_t env_offset,
                           float* state, int64_t ld, int32_t* time, const uint8_t* mask, uint64_t seed, uint64_t tick,
                           const uint64_t* tick_base_dev, void* stream);

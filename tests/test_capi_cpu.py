@@ -3,6 +3,7 @@ the library loads, exports every symbol include/aqua_hip.h declares, packs obsta
 documented, rejects bad arguments with the documented codes, and the product refuses to run
 without a HIP device (no CPU fallback)."""
 import ctypes
+import sys
 import os
 import re
 
@@ -229,6 +230,60 @@ def test_registry_and_presets_match_the_reference_ids():
     assert np.array_equal(presets.rows_from(True), presets.DEFAULT5) and presets.rows_from(False).shape == (0, 5)
     with pytest.raises(Exception):
         presets.rows_from([(np.array([1, 2]), "x", 3)])
+
+
+def test_registration_with_a_gym_like_module(monkeypatch):
+    """gym is absent from the image, so the registration branch of gym_aqua/__init__.py is driven with a stand-in
+    `gym.envs.registration` module: the six ids of the reference (gym_aqua/__init__.py:4-41), its entry points, its
+    keyword presets; a second import keeps the first registration; gymnasium is never asked."""
+    import importlib
+    import types
+    calls = []
+
+    def register(id=None, entry_point=None, kwargs=None, **extra):
+        if any(c[0] == id for c in calls):
+            raise RuntimeError("Cannot re-register id: %s" % id)
+        calls.append((id, entry_point, kwargs))
+
+    gym = types.ModuleType("gym")
+    gym.Env = type("Env", (object,), {})
+    gym.envs = types.ModuleType("gym.envs")
+    gym.envs.registration = types.ModuleType("gym.envs.registration")
+    gym.envs.registration.register = register
+    for name, mod in (("gym", gym), ("gym.envs", gym.envs), ("gym.envs.registration", gym.envs.registration)):
+        monkeypatch.setitem(sys.modules, name, mod)
+
+    class Refuse(types.ModuleType):
+        def __getattr__(self, name):
+            raise AssertionError("gymnasium must not be used (the classes speak classic gym's protocol)")
+    monkeypatch.setitem(sys.modules, "gymnasium", Refuse("gymnasium"))
+    import gym_aqua
+    try:
+        importlib.reload(gym_aqua)
+        assert sorted(c[0] for c in calls) == sorted("%s-v%d" % (c, v) for c in ("AquaEnv", "AquaContinuousEnv") for v in (0, 1, 2))
+        by_id = {c[0]: c for c in calls}
+        assert by_id["AquaEnv-v0"][1] == "gym_aqua.envs:AquaEnv" and by_id["AquaEnv-v0"][2] == {}
+        assert by_id["AquaContinuousEnv-v1"][1] == "gym_aqua.envs:AquaContinuousEnv" and by_id["AquaContinuousEnv-v1"][2] == {"obstacles": True}
+        v2 = by_id["AquaEnv-v2"][2]["obstacles"]            # the reference's `difficult_obstacles`, in its own tuple format
+        want = [((15, 70), "c", 5), ((25, 40), "r", (10, 10)), ((40, 80), "r", (10, 10)), ((55, 20), "c", 10),
+                ((60, 55), "r", (20, 20)), ((85, 75), "c", 5)]
+        assert len(v2) == 6
+        for got, (centre, kind, size) in zip(v2, want):
+            assert tuple(got[0]) == centre and got[1] == kind and np.all(np.asarray(got[2]) == np.asarray(size))
+        assert by_id["AquaContinuousEnv-v2"][2]["obstacles"] is v2
+        n = len(calls)
+        importlib.reload(gym_aqua)                       # re-import: "Cannot re-register" is swallowed, nothing is added
+        assert len(calls) == n
+
+        def broken(**kw):
+            raise ValueError("something else went wrong")
+        gym.envs.registration.register = broken
+        with pytest.raises(ValueError):
+            importlib.reload(gym_aqua)                   # any other failure is not hidden
+    finally:
+        for name in ("gym", "gym.envs", "gym.envs.registration", "gymnasium"):
+            monkeypatch.delitem(sys.modules, name, raising=False)
+        importlib.reload(gym_aqua)
 
 
 def test_spaces_lookalikes():
