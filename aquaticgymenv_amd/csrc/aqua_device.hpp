@@ -346,17 +346,27 @@ __device__ __forceinline__ ExactMotion exact_motion_continuous(double vl, double
 //   t32  float32 [K][6][ld]   row j of world i at t32[(6 j + c) ld + i],  c = cx, cy, hx, hy, r2, w  (ObstF's fields;
 //                             an absent row has r2 = -3e38 and never wins a minimum)
 //   t64  float64 [K][5][ld]   the reference's own row (cx, cy, kind, a, b; kind < 0: absent), for the float64 path
+// A lane names its world as a wave-uniform tile base (t32 / t64 already advanced to the tile's first world) plus a
+// 32-bit offset inside the tile: every access is then `global_load v, voffset, s[base]` -- the row and column arithmetic
+// runs on the scalar unit and no lane holds a 64-bit address (with per-lane addresses the per-world step kernel needed
+// 187 registers: two wavefronts per SIMD).
 struct WorldTable {
-    const float* t32;
-    const double* t64;
+    const float* t32;           // + tile
+    const double* t64;          // + tile (NULL where the float64 path is not used)
     int64_t ld;
-    int64_t i;                  // this lane's world
+    uint32_t off;               // this lane's world inside the tile
 };
+template <typename T>
+__device__ __forceinline__ T world_ld(const T* base, uint32_t elem)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * static_cast<uint32_t>(sizeof(T)));
+}
 __device__ __forceinline__ ObstF world_row(const WorldTable& t, int j)
 {
     ObstF r;
-    const float* p = t.t32 + (6 * j) * t.ld + t.i;
-    r.cx = p[0]; r.cy = p[t.ld]; r.hx = p[2 * t.ld]; r.hy = p[3 * t.ld]; r.r2 = p[4 * t.ld]; r.w = p[5 * t.ld];
+    const float* p = t.t32 + (6 * j) * t.ld;
+    r.cx = world_ld(p, t.off); r.cy = world_ld(p + t.ld, t.off); r.hx = world_ld(p + 2 * t.ld, t.off);
+    r.hy = world_ld(p + 3 * t.ld, t.off); r.r2 = world_ld(p + 4 * t.ld, t.off); r.w = world_ld(p + 5 * t.ld, t.off);
     r.pad[0] = r.pad[1] = 0.0f;
     return r;
 }
@@ -404,7 +414,7 @@ __device__ __noinline__ ExactOut exact_step_impl(float fx, float fy, float fth, 
         double o[5];
         if constexpr (PER_WORLD) {
 #pragma unroll
-            for (int c5 = 0; c5 < 5; ++c5) o[c5] = wt.t64[(5 * k + c5) * wt.ld + wt.i];
+            for (int c5 = 0; c5 < 5; ++c5) o[c5] = world_ld(wt.t64 + (5 * k + c5) * wt.ld, wt.off);
         } else {
 #pragma unroll
             for (int c5 = 0; c5 < 5; ++c5) o[c5] = obst64[5 * k + c5];
@@ -491,9 +501,13 @@ __device__ __forceinline__ float quick_min(float mo, float xn, float yn, const Q
 // QUICK: the first look reads the quick table (k.qc0, k.qr0, k.quick) instead of walking the rows --
 // QUICK_ALWAYS: the caller knows the table has one; QUICK_IF_PRESENT: when k.quick is not NULL (wave-uniform).
 enum : int { QUICK_NEVER = 0, QUICK_ALWAYS = 1, QUICK_IF_PRESENT = 2 };
-template <bool PER_WORLD = false, int QUICK = QUICK_NEVER>
+// KREG > 0 (PER_WORLD only): the caller has read the lane's first KREG rows into registers (`regs`, loaded with the
+// state, one memory round trip for everything; rows past the table's end repeat its last row, which leaves a minimum
+// unchanged) and the first look is arithmetic only; the second look and the float64 path (rare) still read `wt`.
+template <bool PER_WORLD = false, int QUICK = QUICK_NEVER, int KREG = 0>
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
-                                          const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr)
+                                          const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr,
+                                          const ObstF* regs = nullptr)
 {
     float s, c;
     sincos_bounded(e.th + h, s, c);
@@ -508,7 +522,14 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
 
     const float mc = fminf(fminf(xn, yn) - 2.5f, 97.5f - fmaxf(xn, yn));
     float mo = 3.0e38f;                                    // min over obstacles of d^2 - R^2
-    if constexpr (PER_WORLD) {
+    if constexpr (PER_WORLD && KREG > 0) {
+#pragma unroll
+        for (int j = 0; j < KREG; ++j) {                   // (same operations per row as below: same bits)
+            const float dx = fmaxf(fabsf(xn - regs[j].cx) - regs[j].hx, 0.0f);
+            const float dy = fmaxf(fabsf(yn - regs[j].cy) - regs[j].hy, 0.0f);
+            mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -regs[j].r2)));
+        }
+    } else if constexpr (PER_WORLD) {
 #pragma unroll 2
         for (int j = 0; j < k.K; ++j) {                    // a circle is a box with zero half extents: same bits
             const ObstF r = world_row(*wt, j);
@@ -566,6 +587,9 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
         // band of THAT obstacle's radius, 2.5 (R + BAND) BAND_TIGHT + 4 ulp(R^2) -- not R_max's, which for the
         // R = 2.5 of every rectangle would be several times wider than its own in distance.
         if constexpr (PER_WORLD) {
+            // a cold path (a few per cent of the wavefronts): one row at a time.  Unrolled, the compiler keeps forty
+            // loads and their addresses in flight here and this loop alone sets the kernel's register count (156-187)
+#pragma unroll 1
             for (int j = 0; j < k.K; ++j) {
                 const ObstF r = world_row(*wt, j);
                 const float dx = fmaxf(fabsf((xn - r.cx) + xlo) - r.hx, 0.0f);
@@ -753,7 +777,7 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // lanes read the same addresses, so a row costs the group one memory transaction per field.  Rows are read two at
 // a time inside the attempt loop (measured: all rows up front, 40 more live registers, made the masked reset
 // launch 10.2 us instead of 8.8; one world per lane with the rows cached: 10 us).
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2;
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_WORLD8 = -3;
 template <int G, int ROWS = 0>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
@@ -774,6 +798,15 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
     const float W = 0.05f * static_cast<float>(waves);
     const float heading = fmaf(TWO_PI_F, u_01(rw[0]), -PI_F);
 
+    // ROWS == RESEED_WORLD8: the group's table has at most eight rows (K <= 8, the caller's promise): all of them are read
+    // here, in flight with the draws -- ONE memory round trip instead of one per pair of rows inside the attempt loop
+    // (under the step's memory traffic a dependent round trip is ~2.5 us, and four of them made the re-seeding blocks
+    // of the per-world next-step kernel its longest chain).  Rows past the table's end repeat its last row.
+    ObstF wr[ROWS == RESEED_WORLD8 ? 8 : 1];
+    if constexpr (ROWS == RESEED_WORLD8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wr[j] = world_row(*wt, j < K ? j : K - 1);
+    }
     float gx = 25.0f, gy = 80.0f, bx = 85.0f, by = 45.0f, bt = 0.0f;
     bool goal_found = !active || !random_goal;
     bool boat_done = !active || !random_boat;
@@ -816,7 +849,11 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
             }
+        } else if constexpr (ROWS == RESEED_WORLD8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) test(wr[j].cx, wr[j].cy, wr[j].hx, wr[j].hy, wr[j].r2);
         } else if constexpr (ROWS == RESEED_WORLD) {
+#pragma unroll 1
             for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
                 const ObstF r0 = world_row(*wt, j), r1 = world_row(*wt, j + 1 < K ? j + 1 : j);
                 test(r0.cx, r0.cy, r0.hx, r0.hy, r0.r2);
@@ -876,7 +913,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_WORLD8) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

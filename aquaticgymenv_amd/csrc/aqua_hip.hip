@@ -1106,7 +1106,19 @@ struct TablesShared {
 };
 // MODE: AQUA_RESET_NONE, AQUA_RESET_SAME_STEP (restart inside the launch, below), AQUA_RESET_NEXT_STEP (the stepping
 // role of step_tables_ns_kernel: worlds carrying a restart marker do not step, as in step_ns_kernel).
-template <int AK, int MODE>
+// KREG: tables of at most KREG rows (host-selected; 0: any length).  The lane's rows are then loaded WITH its state --
+// uniform row base + the lane's 32-bit offset, forty loads in flight behind the nine of the state, one memory round trip
+// -- instead of two rows at a time after the move is known (three dependent round trips for eight rows, and 64-bit
+// per-lane addresses that cost the kernel 187 registers: two wavefronts per SIMD).
+#ifndef AQUA_TABLES_KREG
+#define AQUA_TABLES_KREG 8
+#endif
+#ifndef AQUA_TABLES_RESEED_ALL                // re-seeding groups read all rows of their table at once (tables of <= 8 rows)
+#define AQUA_TABLES_RESEED_ALL 1
+#endif
+static_assert(AQUA_TABLES_KREG == 0 || AQUA_TABLES_KREG == 8, "RESEED_WORLD8 reads eight rows");
+constexpr int TABLES_KREG = AQUA_TABLES_KREG;
+template <int AK, int MODE, int KREG>
 __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
                                                   int64_t tld, float band2, float band2_tight, int64_t tile)
 {
@@ -1133,6 +1145,34 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     else if constexpr (AK == AQUA_ACT_F32X2) {
         avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
         avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
+    }
+    ObstF rows[KREG > 0 ? KREG : 1];
+    if constexpr (KREG > 0) {
+#pragma unroll
+        for (int j = 0; j < KREG; ++j) {
+            const int jj = j < a.K ? j : a.K - 1;         // uniform; a.K >= 1
+            const float* const rb = t32 + (6 * jj) * tld + tile;
+            rows[j].cx = ld_at(rb, o4); rows[j].cy = ld_at(rb + tld, o4); rows[j].hx = ld_at(rb + 2 * tld, o4);
+            rows[j].hy = ld_at(rb + 3 * tld, o4); rows[j].r2 = ld_at(rb + 4 * tld, o4);
+        }
+#ifdef AQUA_TABLES_VIA_LDS                   // A/B only (never defined in the shipped library): the same rows staged through an
+        {                                    // LDS tile [8][5][256] and read back behind a barrier, as north_star sketches it
+            __shared__ float stage[KREG * 5][BLOCK_SMALL];
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                stage[5 * j + 0][threadIdx.x] = rows[j].cx; stage[5 * j + 1][threadIdx.x] = rows[j].cy;
+                stage[5 * j + 2][threadIdx.x] = rows[j].hx; stage[5 * j + 3][threadIdx.x] = rows[j].hy;
+                stage[5 * j + 4][threadIdx.x] = rows[j].r2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KREG; ++j) {
+                rows[j].cx = stage[5 * j + 0][threadIdx.x]; rows[j].cy = stage[5 * j + 1][threadIdx.x];
+                rows[j].hx = stage[5 * j + 2][threadIdx.x]; rows[j].hy = stage[5 * j + 3][threadIdx.x];
+                rows[j].r2 = stage[5 * j + 4][threadIdx.x];
+            }
+        }
+#endif
     }
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K; k.Kc = 0;
@@ -1162,10 +1202,10 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
     EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
     const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
-    const WorldTable wt{t32, t64, tld, tile + o};
+    const WorldTable wt{t32 + tile, t64 + tile, tld, o};
     float rew;
     uint32_t code;
-    const bool knife = fast_step<true>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt) && live;
+    const bool knife = fast_step<true, QUICK_NEVER, KREG>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt, rows) && live;
     if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step_world(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.band2,
@@ -1211,10 +1251,10 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
-            const WorldTable own{t32, nullptr, tld, tile + i};
-            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i,
-                                                                          tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
-                                                                          nullptr, nullptr, 0, &own);
+            const WorldTable own{t32 + tile, nullptr, tld, i};
+            const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 && AQUA_TABLES_RESEED_ALL) ? RESEED_WORLD8 : RESEED_WORLD>(
+                active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
+                nullptr, nullptr, nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
                 st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
                 st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
@@ -1226,14 +1266,19 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     }
 }
 
-template <int AK, bool RESTART>
-__global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
+// registers: left to itself the compiler keeps the rows of several obstacles in flight per lane (187 VGPRs: two
+// wavefronts per SIMD, two blocks per CU, the grid runs in 2.5 rounds); AQUA_TAB_WAVES_PER_EU caps that
+#ifndef AQUA_TAB_WAVES_PER_EU
+#define AQUA_TAB_WAVES_PER_EU 2
+#endif
+template <int AK, bool RESTART, int KREG>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(AQUA_TAB_WAVES_PER_EU, 8))) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
     tick_housekeeping();
-    tables_step_block<AK, RESTART ? AQUA_RESET_SAME_STEP : AQUA_RESET_NONE>(a, t32, t64, tld, band2, band2_tight,
-                                                                             static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
+    tables_step_block<AK, RESTART ? AQUA_RESET_SAME_STEP : AQUA_RESET_NONE, KREG>(a, t32, t64, tld, band2, band2_tight,
+                                                                                   static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
 }
 
 // Next-step restart with per-world tables: step_ns_kernel's launch split by role (same markers in the time row, same
@@ -1242,8 +1287,8 @@ __global__ __launch_bounds__(BLOCK_SMALL) void step_tables_kernel(const StepArgs
 // Nothing of the re-seeding chain -- four dependent global round trips for the rows of a group's table -- is on the
 // step's path any more, which is what the same-step form pays for (17.5 us per step at 262 144 worlds, 8 rows).
 static_assert(NS_TILE == BLOCK_SMALL, "the stepping role of the per-world next-step kernel is one tables_step_block per block");
-template <int AK, bool INTERLEAVE>
-__global__ __launch_bounds__(NS_BLOCK) void step_tables_ns_kernel(const StepArgs a, const float* __restrict__ t32,
+template <int AK, bool INTERLEAVE, int KREG>
+__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_TAB_WAVES_PER_EU, 8))) void step_tables_ns_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
@@ -1253,9 +1298,14 @@ __global__ __launch_bounds__(NS_BLOCK) void step_tables_ns_kernel(const StepArgs
     int64_t role_index;
     if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
     if (!reseed_role) {
-        tables_step_block<AK, AQUA_RESET_NEXT_STEP>(a, t32, t64, tld, band2, band2_tight, role_index * NS_TILE);
+#ifndef AQUA_NS_NOMAIN                       // (timing experiment: the re-seeding blocks alone, on a synthetic pending set)
+        tables_step_block<AK, AQUA_RESET_NEXT_STEP, KREG>(a, t32, t64, tld, band2, band2_tight, role_index * NS_TILE);
+#endif
         return;
     }
+#ifdef AQUA_NS_NOWORK                        // (timing experiment: the stepping blocks alone)
+    return;
+#endif
     __builtin_amdgcn_s_setprio(3);
     static_assert(RESET_SCAN == NS_SCAN && RESET_SCAN_ROWS == NS_SCAN_ROWS, "one scan shape for both re-seeding kernels");
     constexpr int WAVES = NS_BLOCK / 64;
@@ -1274,7 +1324,12 @@ __global__ __launch_bounds__(NS_BLOCK) void step_tables_ns_kernel(const StepArgs
 #pragma unroll
     for (int j = 0; j < NS_SCAN_ROWS; ++j) {              // wavefront-private compaction: ballot + prefix count
         const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
+#ifdef AQUA_NS_NOMAIN
+        const bool p = static_cast<int64_t>(i) < rem && tw[j] != restart &&
+                       ((static_cast<uint32_t>(base) + i) * 2654435761u + static_cast<uint32_t>(tick) * 40503u) % 54u == 0u;
+#else
         const bool p = static_cast<int64_t>(i) < rem && tw[j] == restart;
+#endif
         const uint64_t m = __ballot(p);
         if (p) sh.list[wave][n_mine + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = static_cast<uint16_t>(i);
@@ -1294,11 +1349,12 @@ __global__ __launch_bounds__(NS_BLOCK) void step_tables_ns_kernel(const StepArgs
         uint32_t seg = 0;
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
-        const int64_t i = base + (active ? sh.list[seg][q - first[seg]] : 0);      // an idle group reads a world that exists
-        const WorldTable own{t32, nullptr, tld, i};
-        const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
-                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
-                                                                      nullptr, 0, &own);
+        const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
+        const int64_t i = base + local;
+        const WorldTable own{t32 + base, nullptr, tld, local};
+        const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 && AQUA_TABLES_RESEED_ALL) ? RESEED_WORLD8 : RESEED_WORLD>(
+            active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
+            nullptr, nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             st1(a.state + 0 * ld + i, f.x); st1(a.state + 1 * ld + i, f.y); st1(a.state + 2 * ld + i, f.th);
             st1(a.state + 3 * ld + i, f.gx); st1(a.state + 4 * ld + i, f.gy);
@@ -1354,8 +1410,9 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
 #pragma unroll 1
         for (int j = 0; j < RESET_SCAN_ROWS; ++j) {
             if (!sel[j]) continue;
-            const int64_t i = base + j * BLOCK_SMALL + threadIdx.x;
-            const WorldTable wt{t32, nullptr, tld, i};
+            const uint32_t local = static_cast<uint32_t>(j * BLOCK_SMALL) + threadIdx.x;
+            const int64_t i = base + local;
+            const WorldTable wt{t32 + base, nullptr, tld, local};
             store(i, reset_env_world(a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat,
                                      a.random_goal, a.K, wt));
         }
@@ -1368,8 +1425,9 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
         uint32_t seg = 0;
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
-        const int64_t i = base + (active ? sh.list[seg][q - first[seg]] : 0);      // an idle group reads a world that exists
-        const WorldTable wt{t32, nullptr, tld, i};
+        const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
+        const int64_t i = base + local;
+        const WorldTable wt{t32 + base, nullptr, tld, local};
         const EnvState e = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
                                                                       a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
                                                                       nullptr, 0, &wt);
@@ -1873,12 +1931,18 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     }
     if (blocks > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
+    const bool regs = TABLES_KREG > 0 && a.K <= TABLES_KREG;   // the rows fit the lanes' registers (see tables_step_block)
+#define AQUA_TAB_MODES(AK, KR)                                                                                                       \
+    do {                                                                                                                             \
+        if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, true, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else hipLaunchKernelGGL((step_tables_kernel<AK, false, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+    } while (0)
 #define AQUA_TAB_LAUNCH(AK)                                                                                                          \
     case AK:                                                                                                                          \
-        if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, true>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else hipLaunchKernelGGL((step_tables_kernel<AK, false>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        if (regs) AQUA_TAB_MODES(AK, TABLES_KREG);                                                                                   \
+        else AQUA_TAB_MODES(AK, 0);                                                                                                  \
         break;
     switch (kind) {
         AQUA_TAB_LAUNCH(AQUA_ACT_U8)
@@ -1891,6 +1955,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
         default: return hipErrorInvalidValue;
     }
 #undef AQUA_TAB_LAUNCH
+#undef AQUA_TAB_MODES
     return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--steps", type=int, default=1000)
-ap.add_argument("--extra", default="")
+ap.add_argument("--tables", action="store_true", help="one obstacle list per world (BENCH8, each obstacle moved by up to 3 units)")
 ap.add_argument("names", nargs="+")
 args = ap.parse_args()
 
@@ -22,7 +22,13 @@ import torch
 from aquaticgymenv_amd import presets, _capi
 from aquaticgymenv_amd.batched import BatchedAqua
 n, steps = %d, %d
-env = BatchedAqua(n, obstacles=presets.BENCH8, seed=0, auto_reset=int(os.environ.get("AQUA_RESET_MODE", "1")), device="cuda:0")
+obst = presets.BENCH8
+if os.environ.get("AQUA_AB_TABLES") == "1":
+    import numpy as np
+    rng = np.random.RandomState(7)
+    obst = np.repeat(presets.BENCH8[None], n, axis=0).astype(np.float64)
+    obst[:, :, 0:2] += rng.uniform(-3, 3, (n, 8, 2))
+env = BatchedAqua(n, obstacles=obst, seed=0, auto_reset=int(os.environ.get("AQUA_RESET_MODE", "1")), device="cuda:0")
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
 acts = torch.randint(0, 3, (100, env.ld), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
@@ -45,6 +51,7 @@ for r in range(args.rounds):
         env = dict(os.environ)
         name, _, mode = name.partition("@")
         env["AQUA_RESET_MODE"] = mode or "1"
+        env["AQUA_AB_TABLES"] = "1" if args.tables else "0"
         if name != "default":
             env["AQUA_HIP_LIB"] = os.path.join(ROOT, "aquaticgymenv_amd", "lib", "variants", "libaqua_hip_%s.so" % name)
         else:
