@@ -313,7 +313,9 @@ def main(argv=None):
     else:
         actions = torch.randint(0, 3, (CHUNK, env.ld), device=dev, generator=gen, dtype=torch.int64).to(torch.uint8)
     words = env.ld // 64
-    block_rows = GATHER_EVERY * CHUNK
+    # rows of one done-mask block = one all-gather: at most GATHER_EVERY chunks, and no more than a region holds (a
+    # 20-step region must not ship a 500-row buffer through RCCL)
+    block_rows = max(chunk, min(GATHER_EVERY * CHUNK, args.steps))
     hist = [torch.zeros((block_rows, words), dtype=torch.int64, device=dev) for _ in range(2)]
     exchange = DoneMaskExchange(block_rows, words, dev) if (world > 1 or args.force_exchange) else None
     runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk)
