@@ -104,6 +104,60 @@ def test_two_rank_rollout_matches_single_process(tmp_path):
     assert np.array_equal(whole, st)
 
 
+class _MaskEnv(object):
+    """what bench.StepRunner needs of an environment, on the CPU: step t of rank r writes the word r * 1000 + t + 1 into
+    its done-mask row (so a gathered block says who wrote which row when)"""
+
+    def __init__(self, rank):
+        self.rank, self._tick = rank, 0
+
+    def rollout(self, steps, actions=None, keep_all=False, done_history=None):
+        for i in range(steps):
+            done_history[i, :] = self.rank * 1000 + self._tick + i + 1
+        self._tick += steps
+
+
+def _bench_worker(rank, world, port, steps, warmup):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        words = 8
+        chunk = min(bench.CHUNK, steps)
+        block_rows = max(chunk, min(bench.GATHER_EVERY * bench.CHUNK, steps))
+        hist = [torch.zeros((block_rows, words), dtype=torch.int64) for _ in range(2)]
+        ex = DoneMaskExchange(block_rows, words, "cpu")
+        assert ex.collective and ex.world == world
+        env = _MaskEnv(rank)
+        runner = bench.StepRunner(env, None, hist, ex, use_graph=False, chunk=chunk)
+        runner.run(warmup)
+        ex.finish()
+        for region in range(3):
+            tick0 = env._tick
+            segs = runner.run(steps)
+            ex.finish()
+            assert env._tick == tick0 + steps and sum(s for _, _, s, _ in segs) == steps
+            # the block gathered last holds, for EVERY rank, the rows of the region's last block
+            buf, row0, s, gathered = segs[-1]
+            assert gathered
+            last_slot = (ex._slot - 1) % len(ex.gathered)
+            block = ex.gathered[last_slot]
+            first_row_tick = tick0 + steps - (row0 + s)          # tick of row 0 of that block
+            for r in range(world):
+                want = r * 1000 + first_row_tick + torch.arange(1, row0 + s + 1, dtype=torch.int64)
+                assert torch.equal(block[r, :row0 + s, 0], want), (rank, region, r)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (230, 7), (1234, 0)])
+def test_bench_runner_exchanges_done_masks_between_two_ranks(steps, warmup):
+    """bench.py's step queue with the real DoneMaskExchange over gloo, two ranks: the driver's short regions (one block of
+    20 rows), a region of full chunks + remainder, and one that wraps the double buffer"""
+    mp.spawn(_bench_worker, args=(2, _free_port(), steps, warmup), nprocs=2, join=True)
+
+
 def test_exchange_world_size_one_cpu():
     ex = DoneMaskExchange(3, 4, "cpu")
     x = torch.arange(12, dtype=torch.int64).reshape(3, 4)
