@@ -12,7 +12,8 @@ obstacles, waves on, Philox noise, auto-reset on.  N > 1: the same batch PER GPU
 range-partitioned global world indices, done-mask all-gather over RCCL on a side stream.
 
 Protocol: W untimed warm-up steps, then REGIONS (5) timed regions of EXACTLY K
-steps each, every region bracketed by barrier + torch.cuda.synchronize() on both sides and reduced
+steps each, every region bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's clock
+stops when ITS queue has drained, steps and done-mask gathers; the barrier follows) and reduced
 with MAX over the ranks; the MEDIAN region is the one reported (`value`, `ms_per_step`; all five are
 listed under `regions_ms`).  Steps are queued as replays of captured HIP graphs of min(CHUNK, K) steps
 (+ one graph for the remainder), so that any K >= 1 and W >= 0 runs the same way.  Inputs are resident
@@ -322,16 +323,23 @@ def main(argv=None):
     runner.prepare(args.warmup)
     runner.prepare(args.steps, timing=True)
 
-    def fence():
+    def drain():
+        """everything this rank queued has run: the steps, and the done-mask gathers behind them on the side stream"""
         if exchange is not None:
             exchange.finish()
         torch.cuda.synchronize()
+
+    def rendezvous():
+        """barrier + synchronize: the closing bracket of one region is the opening bracket of the next.  The clock of a
+        region stops at this rank's own drain() -- the region's time is the MAX over the ranks of that, which is when the
+        slowest rank was done; the barrier's own latency is not part of any region"""
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     runner.run(args.warmup)
-    fence()
+    drain()
+    rendezvous()
     x_before = float(env.state[0, :n].double().sum().item())
     walls, events, graph_ms, segs = [], [], [], []
     # a region that is ONE timed graph carries its own event-record nodes: no stream events (two host calls less inside
@@ -346,8 +354,9 @@ def main(argv=None):
         segs = runner.run(args.steps)
         if not in_graph:
             e1.record()
-        fence()
+        drain()
         walls.append(time.perf_counter() - t0)
+        rendezvous()
         events.append(None if in_graph else e0.elapsed_time(e1))   # ms, on the stream the step kernels are launched on
         graph_ms.append(runner.region_graph_ms(segs) if in_graph else None)
     if in_graph and not all(g is not None and g > 0.0 for g in graph_ms):
