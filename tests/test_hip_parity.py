@@ -690,10 +690,13 @@ def test_fused_rollout_equals_stepwise(torch, continuous, mode):
     assert (outs[0][3] != 0).sum() > 0
 
 
+@pytest.mark.parametrize("T", [1, 2, 16], ids=["one_step_graph", "two_step_graph", "sixteen_step_graph"])
 @pytest.mark.parametrize("reset_mode", [1, 2], ids=["same_step", "next_step"])
-def test_graph_replay_equals_eager(torch, reset_mode):
+def test_graph_replay_equals_eager(torch, reset_mode, T):
+    """replays of a captured rollout draw fresh noise: the graph advances its device-resident tick base itself (its first
+    launch copies the base, its last one stores base + T; a one-step graph keeps the tick kernel)"""
     from aquaticgymenv_amd import presets
-    n, T = 30000, 16
+    n = 30000
     res = []
     for mode in ("eager", "graph"):
         env = _make(torch, n, presets.BENCH8, seed=8, auto_reset=reset_mode)
