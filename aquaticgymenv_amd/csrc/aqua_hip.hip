@@ -1,16 +1,19 @@
 // aqua_hip.hip -- kernels and C ABI (include/aqua_hip.h) of the batched AquaEnv hot path, gfx950 only.
 //
 // Kernels (reference: AquaEnv.step, gym_aqua/envs/aqua.py:135-213; AquaEnv.reset, aqua.py:100-126)
-//   step_ns_kernel<AK, SMALL_TABLE>  one launch per batched step, next-step restart (auto_reset 2): the launch is
-//                          split by role -- a few re-seeding blocks at the head of the grid, stepping blocks of
-//                          256 worlds (one per lane) behind them -- with no synchronisation between the two.
-//                          The benchmarked kernel.
-//   step_kernel<AK>        one launch per batched step, no restart (auto_reset 0) or restart in the same launch
+//   step_ns_kernel<AK, SMALL_TABLE, INTERLEAVE>  one launch per batched step, next-step restart (auto_reset 2): the launch
+//                          is split by role -- re-seeding blocks (at the head of a one-round grid; one in every five
+//                          blocks, on the XCD of its stepping neighbours, in larger grids) and stepping blocks of 256
+//                          worlds (one per lane) -- with no synchronisation between the two.  The benchmarked kernel.
+//   step_kernel<AK, SMALL, RESTART>  one launch per batched step, no restart (auto_reset 0) or restart in the same launch
 //                          (auto_reset 1): 1024-world tiles, finished worlds re-seeded after one barrier.
 //   rollout_kernel<AK>     T steps in one launch with the world state held in registers.
+//   step_tables_kernel / step_tables_ns_kernel / reset_tables_kernel   the same three for batches in which every world
+//                          has its own obstacle table.
 //   reset_kernel           masked reset.   obs_norm_kernel  the DQN's normalised observation after a reset.
 //   ring_write_kernel<T>   one batch of rows into consecutive slots of a replay ring.
-//   tick_kernel            *tick_base += delta (tail node of a captured rollout graph).
+//   tick_kernel            *tick_base += delta (tail node of a captured fused rollout or one-step graph; the per-step
+//                          rollouts advance their tick base themselves, tick_housekeeping()).
 // All of it is coalesced float/integer streaming work on struct-of-arrays rows; no MFMA anywhere (there is
 // no contraction to feed it).  Arithmetic shared by the kernels lives in aqua_device.hpp.
 //
