@@ -221,6 +221,20 @@ def usable_cores():
     return cores
 
 
+def host_info():
+    """what the CPU baselines ran on: model name (/proc/cpuinfo), logical CPUs the OS shows, cores this process may use"""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cores": usable_cores()}
+
+
 def cpu_baselines(args, obstacles):
     """Timed on this host's cores, rank 0 at N = 1 only, bounded samples of the same workload (random actions,
     reset on done, the same obstacle set):
@@ -417,6 +431,7 @@ def main(argv=None):
         }
         if cpu is not None:
             result["cpu_baseline"], result["cpu_baseline_1core"], result["cpu_baseline_c"] = cpu
+            result["host"] = host_info()
         if args.extras and world == 1:
             result["extras"] = extras(env, torch, n, a_bytes)
         if args.per_world_tables and world == 1:
