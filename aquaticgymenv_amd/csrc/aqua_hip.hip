@@ -644,13 +644,7 @@ static_assert(NS_SCAN % NS_TILE == 0, "a re-seeding block covers whole stepping 
 // batches of at least this many worlds interleave the two roles through the grid.  Measured per step, interleaved vs
 // head-of-grid (profiles/r02/ab_interleave.txt): 16.7 M 215 vs 288 us, 8.4 M 98 vs 106, 6.3 M 90 vs 86, 4.2 M 63 vs 61,
 // 1 M 14.6 vs 14.3, 262 144 5.60 vs 5.55
-#ifndef AQUA_NS_INTERLEAVE_MIN
-#define AQUA_NS_INTERLEAVE_MIN (1 << 19)
-#endif
-constexpr int64_t NS_INTERLEAVE_MIN = AQUA_NS_INTERLEAVE_MIN;
-#ifndef AQUA_NS_XCD_GROUPS
-#define AQUA_NS_XCD_GROUPS 1
-#endif
+constexpr int64_t NS_INTERLEAVE_MIN = 1 << 19;
 
 __device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static_cast<int32_t>(tick & 1u); }
 __device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
@@ -751,9 +745,6 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
 // one round of blocks, and a kernel that needs more than 512 / 5 registers per lane leaves some blocks waiting for a
 // slot (a second round: +0.5 us per launch, measured with 82 registers -> 88 allocated -> 5 wavefronts per SIMD and
 // not one to spare).  Asking for at least 6 wavefronts per SIMD caps the kernel at 80 registers.
-#ifndef AQUA_NS_WAVES_PER_EU
-#define AQUA_NS_WAVES_PER_EU 6
-#endif
 // Which role, which tile (next-step kernels).  A grid of ONE round of blocks (262 144 worlds fill the 256 CUs exactly
 // once) starts its re-seeding blocks first -- theirs is the longest chain.  A grid of many rounds would run thousands of
 // re-seeding blocks (latency-bound, three wavefronts of four busy, no memory traffic) before the first world is stepped,
@@ -769,13 +760,9 @@ __device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, in
         // members of a group are blocks x + 8 (5 q + m), m = 0..4, of group 8 q + x: one XCD, one L2 -- the time row the
         // re-seeding block scans is the one its stepping neighbours read.
         constexpr uint32_t PER = NS_SCAN / NS_TILE + 1;
-#if AQUA_NS_XCD_GROUPS
         const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
         const uint32_t q = j / PER, member = j - q * PER;
         const uint32_t group = q * 8u + x;
-#else
-        const uint32_t group = blockIdx.x / PER, member = blockIdx.x - group * PER;
-#endif
         reseed_role = member == 0;
         role_index = reseed_role ? static_cast<int64_t>(group) : static_cast<int64_t>(group) * (PER - 1) + (member - 1);
         if (static_cast<int64_t>(group) >= a.reseed_blocks) return false;    // the grid is rounded up to whole sets of 8 groups
@@ -790,7 +777,7 @@ __device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, in
 // INTERLEAVE: the grid layout (chosen on the host by batch size, like SMALL_TABLE: one kernel per case keeps the SGPR
 // file of the one-round case -- the benchmarked one -- exactly as tight as it was)
 template <int AK, bool SMALL_TABLE, bool INTERLEAVE>
-__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_NS_WAVES_PER_EU, 8))) void step_ns_kernel(const StepArgs a)
+__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void step_ns_kernel(const StepArgs a)
 {
     __shared__ NsReseedShared sh;
     // Everything the prologue needs from the kernel-argument segment is fetched in ONE batch, ahead of the
@@ -1113,14 +1100,7 @@ struct TablesShared {
 // uniform row base + the lane's 32-bit offset, forty loads in flight behind the nine of the state, one memory round trip
 // -- instead of two rows at a time after the move is known (three dependent round trips for eight rows, and 64-bit
 // per-lane addresses that cost the kernel 187 registers: two wavefronts per SIMD).
-#ifndef AQUA_TABLES_KREG
-#define AQUA_TABLES_KREG 8
-#endif
-#ifndef AQUA_TABLES_RESEED_ALL                // re-seeding groups read all rows of their table at once (tables of <= 8 rows)
-#define AQUA_TABLES_RESEED_ALL 1
-#endif
-static_assert(AQUA_TABLES_KREG == 0 || AQUA_TABLES_KREG == 8, "RESEED_WORLD8 reads eight rows");
-constexpr int TABLES_KREG = AQUA_TABLES_KREG;
+constexpr int TABLES_KREG = 8;          // (RESEED_WORLD8 reads eight rows as well)
 template <int AK, int MODE, int KREG>
 __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
                                                   int64_t tld, float band2, float band2_tight, int64_t tile)
@@ -1158,24 +1138,8 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             rows[j].cx = ld_at(rb, o4); rows[j].cy = ld_at(rb + tld, o4); rows[j].hx = ld_at(rb + 2 * tld, o4);
             rows[j].hy = ld_at(rb + 3 * tld, o4); rows[j].r2 = ld_at(rb + 4 * tld, o4);
         }
-#ifdef AQUA_TABLES_VIA_LDS                   // A/B only (never defined in the shipped library): the same rows staged through an
-        {                                    // LDS tile [8][5][256] and read back behind a barrier, as north_star sketches it
-            __shared__ float stage[KREG * 5][BLOCK_SMALL];
-#pragma unroll
-            for (int j = 0; j < KREG; ++j) {
-                stage[5 * j + 0][threadIdx.x] = rows[j].cx; stage[5 * j + 1][threadIdx.x] = rows[j].cy;
-                stage[5 * j + 2][threadIdx.x] = rows[j].hx; stage[5 * j + 3][threadIdx.x] = rows[j].hy;
-                stage[5 * j + 4][threadIdx.x] = rows[j].r2;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KREG; ++j) {
-                rows[j].cx = stage[5 * j + 0][threadIdx.x]; rows[j].cy = stage[5 * j + 1][threadIdx.x];
-                rows[j].hx = stage[5 * j + 2][threadIdx.x]; rows[j].hy = stage[5 * j + 3][threadIdx.x];
-                rows[j].r2 = stage[5 * j + 4][threadIdx.x];
-            }
-        }
-#endif
+        // (the same rows staged through an LDS tile [8][5][256] and read back behind a barrier, as north_star sketches the
+        // per-world list: 14.30 -> 14.67 and 10.64 -> 11.04 us per step -- every element is used by one lane, once)
     }
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K; k.Kc = 0;
@@ -1255,7 +1219,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32 + tile, nullptr, tld, i};
-            const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 && AQUA_TABLES_RESEED_ALL) ? RESEED_WORLD8 : RESEED_WORLD>(
+            const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 ? RESEED_WORLD8 : RESEED_WORLD)>(
                 active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
                 nullptr, nullptr, nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1269,13 +1233,11 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     }
 }
 
-// registers: left to itself the compiler keeps the rows of several obstacles in flight per lane (187 VGPRs: two
-// wavefronts per SIMD, two blocks per CU, the grid runs in 2.5 rounds); AQUA_TAB_WAVES_PER_EU caps that
-#ifndef AQUA_TAB_WAVES_PER_EU
-#define AQUA_TAB_WAVES_PER_EU 2
-#endif
+// (registers: 78-114 by instantiation; the attribute only states the floor of two wavefronts per SIMD.  Asking for more
+// makes the compiler spill to scratch; what brought the count down from 187-242 was not unrolling the cold loops,
+// aqua_device.hpp)
 template <int AK, bool RESTART, int KREG>
-__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(AQUA_TAB_WAVES_PER_EU, 8))) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
@@ -1291,7 +1253,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(AQU
 // step's path any more, which is what the same-step form pays for (17.5 us per step at 262 144 worlds, 8 rows).
 static_assert(NS_TILE == BLOCK_SMALL, "the stepping role of the per-world next-step kernel is one tables_step_block per block");
 template <int AK, bool INTERLEAVE, int KREG>
-__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_TAB_WAVES_PER_EU, 8))) void step_tables_ns_kernel(const StepArgs a, const float* __restrict__ t32,
+__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_tables_ns_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
@@ -1355,7 +1317,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(AQUA_T
         const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
         const int64_t i = base + local;
         const WorldTable own{t32 + base, nullptr, tld, local};
-        const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 && AQUA_TABLES_RESEED_ALL) ? RESEED_WORLD8 : RESEED_WORLD>(
+        const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 ? RESEED_WORLD8 : RESEED_WORLD)>(
             active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
             nullptr, nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1934,7 +1896,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     }
     if (blocks > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
-    const bool regs = TABLES_KREG > 0 && a.K <= TABLES_KREG;   // the rows fit the lanes' registers (see tables_step_block)
+    const bool regs = a.K <= TABLES_KREG;               // the rows fit the lanes' registers (see tables_step_block)
 #define AQUA_TAB_MODES(AK, KR)                                                                                                       \
     do {                                                                                                                             \
         if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
