@@ -777,7 +777,10 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // lanes read the same addresses, so a row costs the group one memory transaction per field.  Rows are read two at
 // a time inside the attempt loop (measured: all rows up front, 40 more live registers, made the masked reset
 // launch 10.2 us instead of 8.8; one world per lane with the rows cached: 10 us).
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_WORLD8 = -3;
+// ROWS == RESEED_HANDOFF8: per-world tables of at most eight rows whose rows the world's OWN lane already holds in
+// registers: it has left them in LDS (`rows` is the group's slot, a per-lane LDS pointer; rows past the table's end
+// repeat its last row) -- no memory round trip at all.  The rare serial scan falls back to the table in memory (`wt`).
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4;
 template <int G, int ROWS = 0>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
@@ -798,15 +801,6 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
     const float W = 0.05f * static_cast<float>(waves);
     const float heading = fmaf(TWO_PI_F, u_01(rw[0]), -PI_F);
 
-    // ROWS == RESEED_WORLD8: the group's table has at most eight rows (K <= 8, the caller's promise): all of them are read
-    // here, in flight with the draws -- ONE memory round trip instead of one per pair of rows inside the attempt loop
-    // (under the step's memory traffic a dependent round trip is ~2.5 us, and four of them made the re-seeding blocks
-    // of the per-world next-step kernel its longest chain).  Rows past the table's end repeat its last row.
-    ObstF wr[ROWS == RESEED_WORLD8 ? 8 : 1];
-    if constexpr (ROWS == RESEED_WORLD8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wr[j] = world_row(*wt, j < K ? j : K - 1);
-    }
     float gx = 25.0f, gy = 80.0f, bx = 85.0f, by = 45.0f, bt = 0.0f;
     bool goal_found = !active || !random_goal;
     bool boat_done = !active || !random_boat;
@@ -827,10 +821,11 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
             const float bdy2 = bdy * bdy;
             hit_b |= fmaf(bdx, bdx, bdy2) <= r2;
         };
-        if constexpr (ROWS > 0) {                        // `rows` is in LDS: a few rows in registers at a time
+        if constexpr (ROWS > 0 || ROWS == RESEED_HANDOFF8) {   // `rows` is in LDS: a few rows in registers at a time
             constexpr int RS = 2;                         // rows in registers at a time
+            constexpr int NROWS = ROWS > 0 ? ROWS : 8;
 #pragma unroll
-            for (int h = 0; h < ROWS; h += RS) {
+            for (int h = 0; h < NROWS; h += RS) {
                 // (the index is laundered so that the reads stay here, next to their use, instead of being
                 // hoisted out of the attempt loop into forty long-lived registers)
                 int first_row = h;
@@ -849,9 +844,6 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
             }
-        } else if constexpr (ROWS == RESEED_WORLD8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) test(wr[j].cx, wr[j].cy, wr[j].hx, wr[j].hy, wr[j].r2);
         } else if constexpr (ROWS == RESEED_WORLD) {
 #pragma unroll 1
             for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
@@ -913,7 +905,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_WORLD8) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

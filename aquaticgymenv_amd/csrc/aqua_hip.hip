@@ -1094,18 +1094,34 @@ struct TablesShared {
     uint32_t count[BLOCK_SMALL / 64];
     uint8_t list[BLOCK_SMALL / 64][64];
 };
+// Hand-off of a restarting world's table rows from its own lane (which loaded them with its state) to the eight lanes
+// that re-seed it: HANDOFF_PER_WAVE slots per wavefront and round (1.2 worlds of a wavefront restart in a step; a wavefront
+// with more takes another round, block-uniform).  The re-seeding then reads NO memory: with the rows fetched from the
+// table a second time -- a dependent round trip behind the step's traffic -- the same-step launch took 13.6-14.4 us and
+// the role-split next-step launch 14.4-15.0 (its re-seeding blocks need the rows of the worlds their scan finds).
+constexpr int HANDOFF_PER_WAVE = 8;
+struct HandoffShared {
+    uint32_t count[BLOCK_SMALL / 64];
+    uint8_t world[BLOCK_SMALL / 64][HANDOFF_PER_WAVE];           // the slot's world (offset in the tile)
+    ObstF rows[BLOCK_SMALL / 64][HANDOFF_PER_WAVE][8];
+};
+constexpr int TABLES_NEXT_STEP_TILE = 3;
 // MODE: AQUA_RESET_NONE, AQUA_RESET_SAME_STEP (restart inside the launch, below), AQUA_RESET_NEXT_STEP (the stepping
-// role of step_tables_ns_kernel: worlds carrying a restart marker do not step, as in step_ns_kernel).
+// role of step_tables_ns_kernel: worlds carrying a restart marker do not step, as in step_ns_kernel),
+// TABLES_NEXT_STEP_TILE (KREG > 0 only: next-step restart inside the tile -- the lane of a world marked "finished last
+// tick" holds that world's rows already and hands them over as the same-step restart does; no re-seeding blocks).
 // KREG: tables of at most KREG rows (host-selected; 0: any length).  The lane's rows are then loaded WITH its state --
 // uniform row base + the lane's 32-bit offset, forty loads in flight behind the nine of the state, one memory round trip
 // -- instead of two rows at a time after the move is known (three dependent round trips for eight rows, and 64-bit
 // per-lane addresses that cost the kernel 187 registers: two wavefronts per SIMD).
-constexpr int TABLES_KREG = 8;          // (RESEED_WORLD8 reads eight rows as well)
+constexpr int TABLES_KREG = 8;          // (HandoffShared holds eight rows per slot as well)
 template <int AK, int MODE, int KREG>
 __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
                                                   int64_t tld, float band2, float band2_tight, int64_t tile)
 {
     constexpr bool RESTART = MODE == AQUA_RESET_SAME_STEP;
+    constexpr bool NS = MODE == AQUA_RESET_NEXT_STEP || MODE == TABLES_NEXT_STEP_TILE;
+    static_assert(MODE != TABLES_NEXT_STEP_TILE || KREG > 0, "the in-tile next-step restart hands over rows held in registers");
     const int64_t ld = a.ld, rem = a.N - tile;
     const int lane = threadIdx.x & 63;
     float* const row0 = a.state + tile;
@@ -1164,8 +1180,8 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     fold_actions<1, AK>(araw, aidx);
     if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
     // next-step restart: restarted last tick -> steps from time 0; any other marker -> the world does not step
-    const int32_t t0 = (MODE == AQUA_RESET_NEXT_STEP && tin == restart_code(tick - 1)) ? 0 : tin;
-    const bool live = valid && !(MODE == AQUA_RESET_NEXT_STEP && t0 < 0);
+    const int32_t t0 = (NS && tin == restart_code(tick - 1)) ? 0 : tin;
+    const bool live = valid && !(NS && t0 < 0);
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
     EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], t0};
     const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
@@ -1189,7 +1205,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     if (live && !(RESTART && done)) {                     // same-step: a finished world's fresh state is written by its group below
         st_at(row0 + 0 * ld, o4, e.x); st_at(row0 + 1 * ld, o4, e.y); st_at(row0 + 2 * ld, o4, e.th);
         st_at(row0 + 5 * ld, o4, e.wx); st_at(row0 + 6 * ld, o4, e.wy);
-        st_at(trow, o4, (MODE == AQUA_RESET_NEXT_STEP && done) ? done_code(tick) : e.t);
+        st_at(trow, o4, (NS && done) ? done_code(tick) : e.t);
         write_norm(a, tile + off, e.x, e.y, e.th, gx[0], gy[0]);
     }
     const uint64_t done_ballot = __ballot(done);
@@ -1197,7 +1213,61 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
         const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
         if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = done_ballot;
     }
-    if constexpr (RESTART) {
+    if constexpr ((RESTART || MODE == TABLES_NEXT_STEP_TILE) && KREG > 0) {
+        // restart inside the tile, rows handed over through LDS (HandoffShared above)
+        __shared__ HandoffShared sh;
+        constexpr int WAVES = BLOCK_SMALL / 64;
+        const int wave = threadIdx.x >> 6;
+        const bool want = RESTART ? done : (valid && tin == done_code(tick - 1));     // same-step: finished now; next-step: last tick
+        const uint64_t want_ballot = __ballot(want);
+        const uint32_t mine = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(want_ballot >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(want_ballot), 0u));
+        if (lane == 0) sh.count[wave] = static_cast<uint32_t>(__builtin_popcountll(want_ballot));
+        for (uint32_t round = 0;; ++round) {
+            const uint32_t lo = round * HANDOFF_PER_WAVE;
+            if (want && mine >= lo && mine < lo + HANDOFF_PER_WAVE) {
+                const uint32_t slot = mine - lo;
+                sh.world[wave][slot] = static_cast<uint8_t>(threadIdx.x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sh.rows[wave][slot][j] = rows[j];
+            }
+            __syncthreads();
+            uint32_t first[WAVES + 1], most = 0;
+            first[0] = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = sh.count[w];
+                most = c > most ? c : most;
+                const uint32_t left = c > lo ? c - lo : 0u;
+                first[w + 1] = first[w] + (left < HANDOFF_PER_WAVE ? left : HANDOFF_PER_WAVE);
+            }
+            const uint32_t n_round = uni(first[WAVES]);
+            constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+            for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_round; qb += PER_BLOCK) {
+                const uint32_t q = qb + (lane / RESET_GROUP);
+                const bool active = q < n_round;
+                uint32_t seg = 0;
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+                const uint32_t slot = active ? q - first[seg] : 0u;
+                const uint32_t i = active ? sh.world[seg][slot] : 0u;                      // an idle group reads a world that exists
+                const WorldTable own{t32 + tile, nullptr, tld, i};
+                const EnvState f = reset_env_group<RESET_GROUP, RESEED_HANDOFF8>(
+                    active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
+                    nullptr, &sh.rows[seg][slot][0], nullptr, 0, &own);
+                if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                    st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
+                    st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
+                    st1(row0 + 5 * ld + i, f.wx); st1(row0 + 6 * ld + i, f.wy);
+                    st1(trow + i, RESTART ? f.t : restart_code(tick));
+                    write_norm(a, tile + i, f.x, f.y, f.th, f.gx, f.gy);
+                }
+            }
+            if (uni(most) <= lo + HANDOFF_PER_WAVE) break;        // block-uniform: every wavefront's worlds have had a slot
+            __syncthreads();                                      // the slots are written again
+        }
+    } else if constexpr (RESTART) {
+        // tables of more than eight rows: the groups read their world's rows from memory
         __shared__ TablesShared sh;
         constexpr int WAVES = BLOCK_SMALL / 64;
         const int wave = threadIdx.x >> 6;
@@ -1219,7 +1289,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32 + tile, nullptr, tld, i};
-            const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 ? RESEED_WORLD8 : RESEED_WORLD)>(
+            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
                 active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
                 nullptr, nullptr, nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1236,14 +1306,14 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
 // (registers: 78-114 by instantiation; the attribute only states the floor of two wavefronts per SIMD.  Asking for more
 // makes the compiler spill to scratch; what brought the count down from 187-242 was not unrolling the cold loops,
 // aqua_device.hpp)
-template <int AK, bool RESTART, int KREG>
+template <int AK, int MODE, int KREG>
 __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
+    static_assert(MODE == AQUA_RESET_NONE || MODE == AQUA_RESET_SAME_STEP || MODE == TABLES_NEXT_STEP_TILE, "one tile per block");
     tick_housekeeping();
-    tables_step_block<AK, RESTART ? AQUA_RESET_SAME_STEP : AQUA_RESET_NONE, KREG>(a, t32, t64, tld, band2, band2_tight,
-                                                                                   static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
+    tables_step_block<AK, MODE, KREG>(a, t32, t64, tld, band2, band2_tight, static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
 }
 
 // Next-step restart with per-world tables: step_ns_kernel's launch split by role (same markers in the time row, same
@@ -1252,7 +1322,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 
 // Nothing of the re-seeding chain -- four dependent global round trips for the rows of a group's table -- is on the
 // step's path any more, which is what the same-step form pays for (17.5 us per step at 262 144 worlds, 8 rows).
 static_assert(NS_TILE == BLOCK_SMALL, "the stepping role of the per-world next-step kernel is one tables_step_block per block");
-template <int AK, bool INTERLEAVE, int KREG>
+template <int AK, bool INTERLEAVE>
 __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_tables_ns_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
@@ -1264,7 +1334,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
     if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
     if (!reseed_role) {
 #ifndef AQUA_NS_NOMAIN                       // (timing experiment: the re-seeding blocks alone, on a synthetic pending set)
-        tables_step_block<AK, AQUA_RESET_NEXT_STEP, KREG>(a, t32, t64, tld, band2, band2_tight, role_index * NS_TILE);
+        tables_step_block<AK, AQUA_RESET_NEXT_STEP, 0>(a, t32, t64, tld, band2, band2_tight, role_index * NS_TILE);
 #endif
         return;
     }
@@ -1317,7 +1387,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
         const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
         const int64_t i = base + local;
         const WorldTable own{t32 + base, nullptr, tld, local};
-        const EnvState f = reset_env_group<RESET_GROUP, (KREG > 0 ? RESEED_WORLD8 : RESEED_WORLD)>(
+        const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
             active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
             nullptr, nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -1887,7 +1957,11 @@ struct TableArgs {
 hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, hipStream_t s)
 {
     StepArgs a = a0;
-    const bool ns = a.auto_reset == AQUA_RESET_NEXT_STEP;
+    const bool regs = a.K <= TABLES_KREG;               // the rows fit the lanes' registers (see tables_step_block)
+    // next-step restart: tables of up to eight rows restart inside the tile (rows handed over through LDS); longer ones
+    // keep the launch split by role (their re-seeding groups read the rows from memory)
+    const bool ns_tile = a.auto_reset == AQUA_RESET_NEXT_STEP && regs;
+    const bool ns = a.auto_reset == AQUA_RESET_NEXT_STEP && !regs;
     const bool interleave = ns && a.N >= NS_INTERLEAVE_MIN;
     int64_t blocks = (a.N + BLOCK_SMALL - 1) / BLOCK_SMALL;
     if (ns) {
@@ -1896,18 +1970,16 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     }
     if (blocks > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
-    const bool regs = a.K <= TABLES_KREG;               // the rows fit the lanes' registers (see tables_step_block)
-#define AQUA_TAB_MODES(AK, KR)                                                                                                       \
-    do {                                                                                                                             \
-        if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, true, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else hipLaunchKernelGGL((step_tables_kernel<AK, false, KR>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-    } while (0)
-#define AQUA_TAB_LAUNCH(AK)                                                                                                          \
-    case AK:                                                                                                                          \
-        if (regs) AQUA_TAB_MODES(AK, TABLES_KREG);                                                                                   \
-        else AQUA_TAB_MODES(AK, 0);                                                                                                  \
+#define AQUA_TAB_ARGS grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight
+#define AQUA_TAB_LAUNCH(AK)                                                                                        \
+    case AK:                                                                                                        \
+        if (ns_tile) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG>), AQUA_TAB_ARGS);        \
+        else if (regs && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG>), AQUA_TAB_ARGS); \
+        else if (regs) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, TABLES_KREG>), AQUA_TAB_ARGS);            \
+        else if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true>), AQUA_TAB_ARGS);                           \
+        else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false>), AQUA_TAB_ARGS);                                  \
+        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0>), AQUA_TAB_ARGS);         \
+        else hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, 0>), AQUA_TAB_ARGS);                                \
         break;
     switch (kind) {
         AQUA_TAB_LAUNCH(AQUA_ACT_U8)
@@ -1920,7 +1992,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
         default: return hipErrorInvalidValue;
     }
 #undef AQUA_TAB_LAUNCH
-#undef AQUA_TAB_MODES
+#undef AQUA_TAB_ARGS
     return hipGetLastError();
 }
 

@@ -586,6 +586,28 @@ def test_per_world_next_step_equals_the_shared_table_kernel(torch):
         assert int((t1[:, :n] != 0).sum()) > n // 4
 
 
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+@pytest.mark.parametrize("rows", [8, 11], ids=["rows8_handoff", "rows11_from_memory"])
+def test_per_world_restart_of_every_world_at_once(torch, mode, rows):
+    """every world of every wavefront restarts in the same step (all past the time limit): the LDS hand-off of the rows
+    (tables of up to 8 rows) then takes eight rounds per tile; == the shared-table kernels bit for bit.  11 rows: the
+    paths that read the rows from memory (role-split launch for the next-step mode)."""
+    from aquaticgymenv_amd import presets
+    n = 3000 + 7
+    base = presets.BENCH8 if rows == 8 else np.concatenate([presets.BENCH8, _obstacle_mix(2, 1, 5)])
+    tables = np.repeat(base[None], n, axis=0)
+    shared = _make(torch, n, base, seed=99, auto_reset=mode)
+    mine = _make(torch, n, tables, seed=99, auto_reset=mode)
+    for e in (shared, mine):
+        e.reset()
+        e.time[:n].fill_(1005)
+    r1, t1 = shared.rollout(6, keep_all=True)
+    r2, t2 = mine.rollout(6, keep_all=True)
+    assert int((t1[0, :n] != 0).sum()) == n                      # everybody finished in the first step
+    assert torch.equal(t1[:, :n], t2[:, :n]) and torch.equal(r1[:, :n], r2[:, :n])
+    assert torch.equal(shared.state[:, :n], mine.state[:, :n]) and torch.equal(shared.time[:n], mine.time[:n])
+
+
 @pytest.mark.parametrize("density", [0.002, 0.03, 0.12, 0.13, 0.6, 1.0])
 def test_per_world_masked_reset_sparse_and_dense_masks_match_the_oracle(torch, oracle, density):
     """the masked reset re-seeds few selected worlds eight lanes per world and many one world per lane (the switch is
