@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64
@@ -20,6 +20,7 @@ SYMBOLS = (
     "aqua_discrete_constants", "aqua_obs_norm_f32",
     "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
     "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
+    "aqua_rollout_tables_fused_f32",
 )
 
 
@@ -65,6 +66,8 @@ def _load():
                                          u64, u64, vp, vp, vp, vp, vp, ci, vp]
     lib.aqua_rollout_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64,
                                             u64, u64, vp, vp, vp, i64, vp, i64, vp, ci, ci, vp]
+    lib.aqua_rollout_tables_fused_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64,
+                                                  u64, u64, vp, vp, vp, i64, ci, vp]
     lib.aqua_reset_tables_f32.argtypes = [pp, vp, ci, i64, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_graph_begin.argtypes = [vp]
     lib.aqua_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
@@ -82,7 +85,8 @@ def _load():
                  "aqua_graph_launch", "aqua_graph_destroy",
                  "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
-                 "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32"):
+                 "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
+                 "aqua_rollout_tables_fused_f32"):
         getattr(lib, name).restype = ci
     if lib.aqua_version() != ABI_VERSION:
         raise ImportError("libaqua_hip.so ABI %d != binding %d: rebuild" % (lib.aqua_version(), ABI_VERSION))

@@ -345,11 +345,14 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
-        if fused and self.per_world:
-            raise NotImplementedError("the fused rollout kernel keeps ONE obstacle table in SGPRs: per-world tables run as "
+        if fused and self.per_world and self.K > 8:
+            raise NotImplementedError("the fused per-world rollout keeps tables of at most 8 rows in LDS: longer ones run as "
                                       "one launch per step (rollout(fused=False) / capture_rollout())")
         with torch.cuda.device(self.device):
-            if self.per_world:
+            if self.per_world and fused:
+                _capi.check(self._rollout_tables_fused(steps, aptr, kind, ald, astride, self._tick, None, reward, term, ostride,
+                                                       self._stream()), "aqua_rollout_tables_fused_f32")
+            elif self.per_world:
                 _capi.check(self._rollout_tables(steps, aptr, kind, ald, astride, self._tick, None, reward, term, ostride,
                                                  done, dstride, 0, self._stream()), "aqua_rollout_tables_f32")
             elif fused:
@@ -376,6 +379,13 @@ class BatchedAqua(object):
                                                  ostride, done.data_ptr(), dstride, self._norm_ptr(), int(self.auto_reset),
                                                  advance, s)
 
+    def _rollout_tables_fused(self, steps, aptr, kind, ald, astride, tick, tick_base, reward, term, ostride, s):
+        return _capi.lib.aqua_rollout_tables_fused_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),
+                                                       self.K, self.ld, self._r_max, self.num_envs, self.env_offset,
+                                                       self.state.data_ptr(), self.ld, self.time.data_ptr(), steps, aptr, kind,
+                                                       ald, astride, self.seed, tick, tick_base, reward.data_ptr(),
+                                                       term.data_ptr(), ostride, int(self.auto_reset), s)
+
     def capture_rollout(self, steps, actions=None, fused=False, keep_all=False, done_history=None, timing=False):
         """Capture `steps` batched steps into a HIP graph.  Noise stays fresh across replays: the
         kernels add a device-resident tick base that the graph's last node advances by `steps`.
@@ -385,8 +395,8 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
-        if fused and self.per_world:
-            raise NotImplementedError("the fused rollout kernel keeps ONE obstacle table in SGPRs: per-world tables are "
+        if fused and self.per_world and self.K > 8:
+            raise NotImplementedError("the fused per-world rollout keeps tables of at most 8 rows in LDS: longer ones are "
                                       "captured as one launch per step (fused=False)")
         self._sync_device_tick()
         cap = torch.cuda.Stream(device=self.device)
@@ -402,7 +412,9 @@ class BatchedAqua(object):
             _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
             try:
                 tb = self._tick_dev.data_ptr()
-                if self.per_world:
+                if self.per_world and fused:
+                    rc = self._rollout_tables_fused(steps, aptr, kind, ald, astride, 0, tb, reward, term, ostride, s)
+                elif self.per_world:
                     rc = self._rollout_tables(steps, aptr, kind, ald, astride, 0, tb, reward, term, ostride, done, dstride, 1, s)
                 elif fused:
                     rc = lib.aqua_rollout_fused_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,

@@ -780,7 +780,10 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // ROWS == RESEED_HANDOFF8: per-world tables of at most eight rows whose rows the world's OWN lane already holds in
 // registers: it has left them in LDS (`rows` is the group's slot, a per-lane LDS pointer; rows past the table's end
 // repeat its last row) -- no memory round trip at all.  The rare serial scan falls back to the table in memory (`wt`).
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4;
+// ROWS == RESEED_SOA8: the same, for a block that keeps the tables of ALL its worlds in LDS as [row][field][lane]
+// (the fused per-world rollout): `rows` points at the world's column, fields RESEED_SOA_STRIDE floats apart.
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA8 = -5;
+constexpr int RESEED_SOA_STRIDE = 256;
 template <int G, int ROWS = 0>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
@@ -840,6 +843,24 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 for (int j = 0; j < RS; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
                 // finish these rows before the next ones are read: without it the vectoriser pairs operations
                 // across ALL rows and keeps the whole table (and sixteen partial results) live at once
+                uint32_t fg = hit_g, fb = hit_b;
+                asm volatile("" : "+v"(fg), "+v"(fb));
+                hit_g = fg != 0u; hit_b = fb != 0u;
+            }
+        } else if constexpr (ROWS == RESEED_SOA8) {
+            const float* const soa = reinterpret_cast<const float*>(rows);
+#pragma unroll
+            for (int h = 0; h < 8; h += 2) {
+                int first_row = h;
+                asm volatile("" : "+v"(first_row));      // (as above: the reads stay next to their use)
+                const float* r = soa + first_row * 5 * RESEED_SOA_STRIDE;
+                float c[2][5];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) c[j][f] = r[(j * 5 + f) * RESEED_SOA_STRIDE];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
                 uint32_t fg = hit_g, fb = hit_b;
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
@@ -905,7 +926,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_SOA8) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

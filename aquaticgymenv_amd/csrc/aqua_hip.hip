@@ -1400,6 +1400,154 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
     }
 }
 
+// ------------------------------------------------------------------ per-world tables: T steps in one launch
+// rollout_kernel for batches in which every world has its own table (of at most eight rows): the state stays in
+// registers for the whole rollout and the block's tables stay in LDS -- 40 floats per world as [row][field][lane], read
+// conflict-free by the world's own lane in every step and, as a broadcast, by the eight lanes that re-seed it.  Here the
+// LDS tile pays (it did not for the one-launch-per-step kernel): every row is used T times.  HBM traffic per
+// world-step: the action in, reward and term out.  Restart protocol, markers and results: rollout_kernel's, i.e. T launches
+// of the per-step kernels bit for bit.
+static_assert(RESEED_SOA_STRIDE == BLOCK_SMALL, "one column of the LDS table tile per lane");
+struct RolloutTablesShared {
+    RolloutShared r;
+    float rows[8 * 5][BLOCK_SMALL];
+};
+
+__device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, const StepArgs& a, uint64_t tick, int64_t block_first_world,
+                                                    RolloutTablesShared& sh, int parity, const float* __restrict__ t32_tile, int64_t tld)
+{
+    constexpr int WAVES = BLOCK_SMALL / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (tk.n == 0 || wave != static_cast<int>(tick & (WAVES - 1))) return;
+    uint32_t first[WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.r.count[parity][w];
+    constexpr uint32_t PER_PASS = 64 / RESET_GROUP;
+    for (uint32_t qb = 0; qb < tk.n; qb += PER_PASS) {
+        const uint32_t q = qb + (lane / RESET_GROUP);
+        const bool active = q < tk.n;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+        const uint32_t owner = sh.r.list[parity][seg][active ? q - first[seg] : 0];
+        const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
+        const WorldTable own{t32_tile, nullptr, tld, owner};
+        const EnvState f = reset_env_group<RESET_GROUP, RESEED_SOA8>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
+                                                                      nullptr, reinterpret_cast<const ObstF*>(&sh.rows[0][owner]), nullptr, 0, &own);
+        if (active && (lane & (RESET_GROUP - 1)) == 0) {
+            float* r = sh.r.result[q];
+            r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
+        }
+    }
+}
+
+template <int AK, int MODE>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 3))) void rollout_tables_kernel(
+    const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
+{
+    __shared__ RolloutTablesShared sh;
+    StepConst k;
+    k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K; k.Kc = 0;
+    k.band2 = band2; k.band2_tight = band2_tight; k.obst = nullptr; k.obst64 = nullptr; k.quick = nullptr;
+    k.touch[0] = k.touch[1] = k.touch[2] = k.touch[3] = 0;
+    const uint64_t tick0 = launch_tick(a);
+    const int64_t N = a.N, ld = a.ld;
+    for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
+         bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+        const int64_t i = bbase + threadIdx.x;
+        const bool valid = i < N;
+        const int64_t ic = valid ? i : N - 1;
+        const uint32_t off = static_cast<uint32_t>(ic - bbase);
+        EnvState e{a.state[0 * ld + ic], a.state[1 * ld + ic], a.state[2 * ld + ic], a.state[3 * ld + ic],
+                   a.state[4 * ld + ic], a.state[5 * ld + ic], a.state[6 * ld + ic], a.time[ic]};
+        __syncthreads();                                   // (a block that iterates: the last tile's columns are no longer read)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int jj = j < a.K ? j : a.K - 1;          // uniform; 1 <= a.K <= 8
+            const float* const rb = t32 + (6 * jj) * tld + bbase;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) sh.rows[j * 5 + f][threadIdx.x] = rb[f * tld + off];
+        }
+        __syncthreads();
+        const WorldTable wt{t32 + bbase, t64 + bbase, tld, off};
+        const uint64_t env = static_cast<uint64_t>(a.env_offset + i);
+        for (int64_t s = 0; s < a.T; ++s) {
+            const uint64_t tick = tick0 + static_cast<uint64_t>(s);
+            const int parity = static_cast<int>(s & 1);
+            bool pending = false, restart = false;
+            ReseedTicket tk{0u, 0u};
+            if constexpr (MODE == AQUA_RESET_NEXT_STEP) {
+                if (e.t == restart_code(tick - 1)) e.t = 0;
+                restart = valid && e.t == done_code(tick - 1);
+                pending = valid && e.t < 0;
+                tk = publish_reseed(restart, sh.r, parity);
+                serve_reseed_tables(tk, a, tick, bbase, sh, parity, t32 + bbase, tld);
+            }
+            int idx = 2;
+            float vl = 0.5f, vr = 0.5f;
+            if constexpr (AK == AQUA_ACT_U8) idx = fold_index(static_cast<const uint8_t*>(a.action)[s * a.action_step_stride + ic]);
+            if constexpr (AK == AQUA_ACT_I32) idx = fold_index(static_cast<const int32_t*>(a.action)[s * a.action_step_stride + ic]);
+            if constexpr (AK == AQUA_ACT_I64) idx = fold_index(static_cast<const int64_t*>(a.action)[s * a.action_step_stride + ic]);
+            if constexpr (AK == AQUA_ACT_F32X2) {
+                const float* base = static_cast<const float*>(a.action) + s * a.action_step_stride;
+                vl = base[ic]; vr = base[a.action_ld + ic];
+            }
+            uint32_t w0[1], w1[1];
+            pair_draws<1, false>(a.seed, env, tick, STREAM_STEP, w0, w1);
+            const float u0 = u_pm1(w0[0]), u1 = u_pm1(w1[0]);
+            if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+                pair_draws<1, false>(a.seed, env, tick, STREAM_ACT, w0, w1);
+                if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(w0[0]);
+                else { vl = sample_thrust(w0[0]); vr = sample_thrust(w1[0]); }
+            }
+            if constexpr (AK == AQUA_ACT_BEARING) idx = bearing_action(e.x, e.y, e.th, e.gx, e.gy);
+            const Motion m = decode_motion<AK>(k, idx, vl, vr);
+            const EnvState before = e;
+            EnvState after = e;
+            float rew;
+            uint32_t code;
+            ObstF rows[8];                                  // this step's copy of the lane's column
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rows[j].cx = sh.rows[j * 5 + 0][threadIdx.x]; rows[j].cy = sh.rows[j * 5 + 1][threadIdx.x];
+                rows[j].hx = sh.rows[j * 5 + 2][threadIdx.x]; rows[j].hy = sh.rows[j * 5 + 3][threadIdx.x];
+                rows[j].r2 = sh.rows[j * 5 + 4][threadIdx.x]; rows[j].w = 1.0f;
+            }
+            const bool knife = fast_step<true, QUICK_NEVER, 8>(after, m.h, m.w, m.chord, u0, u1, k, rew, code, &wt, rows) && valid && !pending;
+            if (any_lane(knife)) {
+                if (knife) {
+                    const ExactOut o = exact_step_world(before.x, before.y, before.th, before.gx, before.gy, before.wx, before.wy,
+                                                        after.t, exact_motion<AK>(m), k.K, k.band2, k.time_limit, wt);
+                    after.x = o.x; after.y = o.y; after.th = o.th; rew = o.reward; code = o.term;
+                }
+            }
+            if (pending) { rew = 0.0f; code = 0u; }
+            else e = after;
+            if (valid) {
+                a.reward[s * a.out_step_stride + i] = rew;
+                a.term[s * a.out_step_stride + i] = static_cast<uint8_t>(code);
+            }
+            const bool done = valid && code != 0u;
+            if constexpr (MODE == AQUA_RESET_NEXT_STEP) {
+                collect_reseed(e, restart, tk, sh.r);
+                if (restart) e.t = restart_code(tick);
+                else if (done) e.t = done_code(tick);
+            } else if constexpr (MODE == AQUA_RESET_SAME_STEP) {
+                const ReseedTicket t1 = publish_reseed(done, sh.r, parity);
+                serve_reseed_tables(t1, a, tick, bbase, sh, parity, t32 + bbase, tld);
+                collect_reseed(e, done, t1, sh.r);
+            }
+        }
+        if (valid) {
+            a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
+            a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
+            a.state[5 * ld + i] = e.wx; a.state[6 * ld + i] = e.wy;
+            a.time[i] = e.t;
+        }
+    }
+}
+
 // Masked reset against per-world tables.  A block reads the mask of RESET_SCAN worlds and compacts the selected ones
 // into an LDS list (ballot + prefix count per wavefront, one barrier).  Few selected (the restart after a step:
 // ~2 % of the worlds): they are re-seeded eight lanes per world like everywhere else -- with one world per lane,
@@ -2072,6 +2220,52 @@ int aqua_rollout_tables_f32(const AquaParams* p, const float* tab32_dev, const d
     }
     if (advance_tick && T == 1) return aqua_tick_advance(tick_words, 1, stream);
     return 0;
+}
+
+int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                                  float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time, int64_t T,
+                                  const void* actions, int action_kind, int64_t action_ld, int64_t action_step_stride,
+                                  uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                                  int64_t out_step_stride, int auto_reset, void* stream)
+{
+    StepArgs a;
+    if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
+    if (K > TABLES_KREG)
+        return fail(AQUA_E_INVALID, "the fused per-world rollout keeps tables of at most %d rows in LDS (K=%d): use aqua_rollout_tables_f32", TABLES_KREG, K);
+    int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
+    if (rc) return rc;
+    TableArgs t;
+    rc = check_tables(t, tab32_dev, tab64_dev, tld, r_max);
+    if (rc) return rc;
+    rc = check_step_buffers(N, actions, action_kind, action_ld, nullptr, 0, reward, term);
+    if (rc) return rc;
+    if (T < 0 || action_step_stride < 0 || out_step_stride < 0) return fail(AQUA_E_INVALID, "negative T or stride");
+    if (N == 0 || T == 0) return 0;
+    a.action = actions; a.action_ld = action_ld; a.action_step_stride = action_step_stride;
+    a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;
+    const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define AQUA_ROLLOUT_TABLES(AK)                                                                                              \
+    case AK:                                                                                                                 \
+        if (auto_reset == AQUA_RESET_NEXT_STEP)                                                                              \
+            hipLaunchKernelGGL((rollout_tables_kernel<AK, AQUA_RESET_NEXT_STEP>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else if (auto_reset == AQUA_RESET_SAME_STEP)                                                                         \
+            hipLaunchKernelGGL((rollout_tables_kernel<AK, AQUA_RESET_SAME_STEP>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else hipLaunchKernelGGL((rollout_tables_kernel<AK, 0>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        break;
+    switch (action_kind) {
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_U8)
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_I32)
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_I64)
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_F32X2)
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_SAMPLE_D)
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_SAMPLE_C)
+        AQUA_ROLLOUT_TABLES(AQUA_ACT_BEARING)
+#undef AQUA_ROLLOUT_TABLES
+        default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "aqua_rollout_tables_fused_f32 launch");
 }
 
 int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, int64_t tld, int64_t N, int64_t env_offset,

@@ -505,7 +505,21 @@ def per_world_tables(torch, np, presets, BatchedAqua, n, dev):
         us = e0.elapsed_time(e1) * 1e3 / (reps * CHUNK)
         out[mode] = {"env_steps_per_s": n / us * 1e6, "us_per_step": us, "launches_per_step": 1,
                      "achieved_GBps": a_bytes * n / us / 1e3, "frac_of_8TBps": a_bytes * n / us / 1e3 / HBM_PEAK_GBPS}
-        del graph, env
+        # the fused per-world rollout (state in registers, tables in LDS; 5 B per world-step): its own line, never `value`
+        fused = env.capture_rollout(CHUNK, actions=actions, fused=True, keep_all=False)
+        for _ in range(3):
+            fused.launch()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fused.launch()
+        e1.record()
+        torch.cuda.synchronize()
+        fus = e0.elapsed_time(e1) * 1e3 / (reps * CHUNK)
+        out[mode + "_fused_rollout"] = {"env_steps_per_s": n / fus * 1e6, "us_per_step": fus, "steps_per_launch": CHUNK,
+                                        "bytes_per_world_step": 5}
+        del graph, fused, env
     return out
 
 

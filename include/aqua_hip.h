@@ -35,8 +35,9 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 3   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
-                                3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed */
+#define AQUA_ABI_VERSION 4   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
+                                3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed;
+                                4: aqua_rollout_tables_fused_f32 */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
@@ -194,6 +195,14 @@ int aqua_rollout_tables_f32(const AquaParams* p, const float* tab32_dev, const d
                             uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
                             int64_t out_step_stride, uint64_t* done_bits, int64_t done_step_stride, float* obs_norm,
                             int auto_reset, int advance_tick, void* stream);
+/* aqua_rollout_fused_f32 with per-world tables of at most 8 rows: T steps in ONE launch, the state in registers and the
+ * block's tables in LDS for the whole rollout (K > 8: AQUA_E_INVALID -- use aqua_rollout_tables_f32).  Results are
+ * identical to aqua_rollout_tables_f32 with the same arguments. */
+int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
+                                  float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time, int64_t T,
+                                  const void* actions, int action_kind, int64_t action_ld, int64_t action_step_stride,
+                                  uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
+                                  int64_t out_step_stride, int auto_reset, void* stream);
 int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, int64_t tld, int64_t N, int64_t env_offset,
                           float* state, int64_t ld, int32_t* time, const uint8_t* mask, uint64_t seed, uint64_t tick,
                           const uint64_t* tick_base_dev, void* stream);

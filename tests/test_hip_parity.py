@@ -565,8 +565,27 @@ def test_per_world_tables_rollout_and_graph_equal_single_steps(torch, mode):
                     assert torch.equal(r[t, :n], want_r[rep * T + t]) and torch.equal(c[t, :n], want_t[rep * T + t])
             assert torch.equal(graph_env.state, ref.state) and torch.equal(graph_env.time, ref.time)
             assert graph_env._tick == ref._tick
+        # the fused rollout (state in registers, the block's tables in LDS): eager and as a replayed graph
+        fused, fgraph = (_make(torch, n, tables, seed=31, auto_reset=mode) for _ in range(2))
+        fused.reset(); fgraph.reset()
+        g = fgraph.capture_rollout(T, actions=acts[:T] if actions == "stored" else actions, fused=True, keep_all=True)
+        for rep in range(3):
+            a = acts[rep * T:(rep + 1) * T] if actions == "stored" else actions
+            r, c = fused.rollout(T, actions=a, fused=True, keep_all=True)
+            for t in range(T):
+                assert torch.equal(r[t, :n], want_r[rep * T + t]) and torch.equal(c[t, :n], want_t[rep * T + t])
+            if actions != "stored":                       # (a graph replays the action rows it captured)
+                r, c = g.launch()
+                torch.cuda.synchronize()
+                for t in range(T):
+                    assert torch.equal(r[t, :n], want_r[rep * T + t]) and torch.equal(c[t, :n], want_t[rep * T + t])
+        assert torch.equal(fused.state, ref.state) and torch.equal(fused.time, ref.time)
+        if actions != "stored":
+            assert torch.equal(fgraph.state, ref.state) and torch.equal(fgraph.time, ref.time)
+    long_tables = _make(torch, 100, _random_tables(rng, 100, 11), seed=1, auto_reset=mode)
+    long_tables.reset()
     with pytest.raises(NotImplementedError):
-        ref.rollout(T, fused=True)
+        long_tables.rollout(T, fused=True)                 # more than 8 rows do not fit the LDS tile
 
 
 def test_per_world_next_step_equals_the_shared_table_kernel(torch):
@@ -606,6 +625,13 @@ def test_per_world_restart_of_every_world_at_once(torch, mode, rows):
     assert int((t1[0, :n] != 0).sum()) == n                      # everybody finished in the first step
     assert torch.equal(t1[:, :n], t2[:, :n]) and torch.equal(r1[:, :n], r2[:, :n])
     assert torch.equal(shared.state[:, :n], mine.state[:, :n]) and torch.equal(shared.time[:n], mine.time[:n])
+    if rows == 8:                                                # ... and the fused per-world rollout
+        fused = _make(torch, n, tables, seed=99, auto_reset=mode)
+        fused.reset()
+        fused.time[:n].fill_(1005)
+        r3, t3 = fused.rollout(6, fused=True, keep_all=True)
+        assert torch.equal(t1[:, :n], t3[:, :n]) and torch.equal(r1[:, :n], r3[:, :n])
+        assert torch.equal(shared.state[:, :n], fused.state[:, :n]) and torch.equal(shared.time[:n], fused.time[:n])
 
 
 @pytest.mark.parametrize("density", [0.002, 0.03, 0.12, 0.13, 0.6, 1.0])
