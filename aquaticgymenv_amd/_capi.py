@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64
@@ -21,7 +21,11 @@ SYMBOLS = (
     "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
     "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
     "aqua_rollout_tables_fused_f32",
+    "aqua_ipc_buffer_create", "aqua_ipc_buffer_ptr", "aqua_ipc_buffer_handle", "aqua_ipc_buffer_destroy", "aqua_ipc_open",
+    "aqua_ipc_close", "aqua_copy_async", "aqua_copy_fanout_async",
 )
+IPC_HANDLE_BYTES = 64
+COPY_ENGINE_WAVES, COPY_ENGINE_DMA = 0, 1
 
 
 class AquaParams(ctypes.Structure):
@@ -78,6 +82,15 @@ def _load():
     lib.aqua_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.aqua_event_destroy.argtypes = [vp]
     lib.aqua_graph_end_timed.argtypes = [vp, ctypes.POINTER(vp), vp, vp]
+    lib.aqua_ipc_buffer_create.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.aqua_ipc_buffer_ptr.argtypes = [vp]
+    lib.aqua_ipc_buffer_ptr.restype = vp
+    lib.aqua_ipc_buffer_handle.argtypes = [vp, ctypes.c_char_p]
+    lib.aqua_ipc_buffer_destroy.argtypes = [vp]
+    lib.aqua_ipc_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    lib.aqua_ipc_close.argtypes = [vp]
+    lib.aqua_copy_async.argtypes = [vp, vp, ctypes.c_size_t, ci, vp]
+    lib.aqua_copy_fanout_async.argtypes = [ctypes.POINTER(vp), ci, vp, ctypes.c_size_t, vp]
     lib.aqua_discrete_constants.argtypes = [ctypes.POINTER(ctypes.c_float)]
     lib.aqua_discrete_constants.restype = None
     for name in ("aqua_pack_obstacles", "aqua_step_f32", "aqua_reset_f32", "aqua_rollout_f32",
@@ -86,7 +99,8 @@ def _load():
                  "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
                  "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
-                 "aqua_rollout_tables_fused_f32"):
+                 "aqua_rollout_tables_fused_f32", "aqua_ipc_buffer_create", "aqua_ipc_buffer_handle", "aqua_ipc_buffer_destroy",
+                 "aqua_ipc_open", "aqua_ipc_close", "aqua_copy_async", "aqua_copy_fanout_async"):
         getattr(lib, name).restype = ci
     if lib.aqua_version() != ABI_VERSION:
         raise ImportError("libaqua_hip.so ABI %d != binding %d: rebuild" % (lib.aqua_version(), ABI_VERSION))

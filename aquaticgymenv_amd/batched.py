@@ -406,7 +406,27 @@ class BatchedAqua(object):
         if timing:
             events = (ctypes.c_void_p(), ctypes.c_void_p())
             for e in events:
-                _capi.check(lib.aqua_event_create(ctypes.byref(e)), "aqua_event_create")
+                rc_ev = lib.aqua_event_create(ctypes.byref(e))
+                if rc_ev != 0:                    # the first event (if it exists) must not outlive the failure
+                    for made in events:
+                        lib.aqua_event_destroy(made)
+                    _capi.check(rc_ev, "aqua_event_create")
+        try:
+            return self._capture(cap, handle, events, steps, actions, fused, aptr, kind, ald, astride, reward, term, ostride,
+                                 done, dstride, timing)
+        except Exception:
+            # a capture that failed (e.g. event-record nodes unsupported: bench.StepRunner.prepare falls back) leaves no
+            # event handles behind, and the current stream is joined with the capture stream either way
+            if events is not None:
+                for e in events:
+                    lib.aqua_event_destroy(e)
+            raise
+        finally:
+            torch.cuda.current_stream(self.device).wait_stream(cap)
+
+    def _capture(self, cap, handle, events, steps, actions, fused, aptr, kind, ald, astride, reward, term, ostride, done, dstride,
+                 timing):
+        torch, lib = self.torch, _capi.lib
         with torch.cuda.device(self.device), torch.cuda.stream(cap):
             s = self._stream()
             _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
@@ -435,9 +455,10 @@ class BatchedAqua(object):
                     rc_end = lib.aqua_graph_end_timed(s, ctypes.byref(handle), events[0], events[1])
                 else:
                     rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
+            if rc != 0 and rc_end == 0:           # the launches failed but a graph was made: do not keep it
+                lib.aqua_graph_destroy(handle)
             _capi.check(rc, "capture rollout")
             _capi.check(rc_end, "aqua_graph_end")
-        torch.cuda.current_stream(self.device).wait_stream(cap)
         g = RolloutGraph(self, handle, steps, reward, term, events)
         g._actions = actions          # keep the action buffer alive as long as the graph
         g.done_history = done if dstride else None

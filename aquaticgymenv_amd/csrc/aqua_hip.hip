@@ -1638,6 +1638,45 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_kernel(const StepArgs a, co
 
 __global__ void tick_kernel(uint64_t* tick_base, uint64_t delta) { *tick_base += delta; }
 
+// The done-mask blocks' way into a receive buffer (the own one, or another GPU's through its IPC mapping): single-wavefront
+// workgroups that copy 16-byte words, four loads in flight per lane; 64 threads, a few registers, no LDS.  The grid grows
+// with the block (one workgroup per 32 KiB, 8 to 256 of them) so that the copy is SHORT: measured on one rank
+// (profiles/r03/exchange_overhead_one_rank.txt) the step kernels of the other stream lose ~2 us per launch for as long as
+// ANY other kernel is resident -- 8 wavefronts that take a millisecond for a 16 MB block cost the step stream as much as
+// RCCL's all-gather does (18 %), the same bytes moved in ~20 us cost nothing measurable.
+constexpr unsigned COPY_BLOCKS_MIN = 8, COPY_BLOCKS_MAX = 256;
+constexpr size_t COPY_BYTES_PER_BLOCK = 32768;
+struct alignas(16) Word16 { unsigned long long lo, hi; };
+template <typename W>
+__global__ __launch_bounds__(64) void copy_words_kernel(W* __restrict__ dst, const W* __restrict__ src, size_t n)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * 64;
+    size_t i = static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const W a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// The same copy into up to eight receive buffers at once (blockIdx.y picks the destination): ONE launch, in stream order
+// behind the last step of a region, delivers the region's last block to every GPU of the node -- no host round trip and
+// no second stream between that step and its copies; its duration is the slowest link's.
+constexpr int COPY_FANOUT_MAX = 8;
+struct CopyFanout { void* dst[COPY_FANOUT_MAX]; };
+template <typename W>
+__global__ __launch_bounds__(64) void copy_fanout_kernel(CopyFanout f, const W* __restrict__ src, size_t n)
+{
+    W* const dst = static_cast<W*>(f.dst[blockIdx.y]);
+    const size_t stride = static_cast<size_t>(gridDim.x) * 64;
+    size_t i = static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const W a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 // ring[r][(cursor + i) % capacity] = src[r][i]: the batch lands in consecutive slots, so both sides are coalesced
 // (the wrap splits at most one wavefront's store)
 template <typename T>
@@ -2412,6 +2451,113 @@ int aqua_event_destroy(AquaEvent* e)
     (void)hipEventDestroy(e->event);
     delete e;
     return 0;
+}
+
+// ------------------------------------------------------------------ buffers other processes of the node can write (done-mask exchange)
+struct AquaIpcBuffer {
+    void* ptr;
+    size_t bytes;
+};
+
+int aqua_ipc_buffer_create(size_t bytes, AquaIpcBuffer** out)
+{
+    if (out == nullptr || bytes == 0) return fail(AQUA_E_INVALID, "out is NULL or bytes == 0");
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (ipc buffer)");
+    if ((e = hipMemset(p, 0, bytes)) != hipSuccess) { (void)hipFree(p); return hip_fail(e, "hipMemset (ipc buffer)"); }
+    *out = new AquaIpcBuffer{p, bytes};
+    return 0;
+}
+
+void* aqua_ipc_buffer_ptr(AquaIpcBuffer* b) { return b ? b->ptr : nullptr; }
+
+int aqua_ipc_buffer_handle(AquaIpcBuffer* b, unsigned char handle[AQUA_IPC_HANDLE_BYTES])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == AQUA_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    if (b == nullptr || handle == nullptr) return fail(AQUA_E_INVALID, "buffer/handle is NULL");
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, b->ptr);
+    if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle");
+    std::memcpy(handle, &h, sizeof(h));
+    return 0;
+}
+
+int aqua_ipc_buffer_destroy(AquaIpcBuffer* b)
+{
+    if (b == nullptr) return 0;
+    (void)hipFree(b->ptr);
+    delete b;
+    return 0;
+}
+
+int aqua_ipc_open(const unsigned char handle[AQUA_IPC_HANDLE_BYTES], void** peer_ptr)
+{
+    if (handle == nullptr || peer_ptr == nullptr) return fail(AQUA_E_INVALID, "handle/peer_ptr is NULL");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    const hipError_t e = hipIpcOpenMemHandle(peer_ptr, h, hipIpcMemLazyEnablePeerAccess);
+    return e == hipSuccess ? 0 : hip_fail(e, "hipIpcOpenMemHandle");
+}
+
+int aqua_ipc_close(void* peer_ptr)
+{
+    if (peer_ptr == nullptr) return 0;
+    const hipError_t e = hipIpcCloseMemHandle(peer_ptr);
+    return e == hipSuccess ? 0 : hip_fail(e, "hipIpcCloseMemHandle");
+}
+
+int aqua_copy_fanout_async(void* const* dsts, int n_dst, const void* src, size_t bytes, void* stream)
+{
+    if (bytes == 0 || n_dst == 0) return 0;
+    if (dsts == nullptr || src == nullptr || n_dst < 0) return fail(AQUA_E_INVALID, "dsts/src is NULL or n_dst < 0");
+    if (bytes % 8 != 0 || !aligned(src, 8)) return fail(AQUA_E_ALIGN, "aqua_copy_fanout_async moves whole 8-byte words");
+    bool wide = bytes % 16 == 0 && aligned(src, 16);
+    for (int j = 0; j < n_dst; ++j) {
+        if (dsts[j] == nullptr) return fail(AQUA_E_INVALID, "destination %d is NULL", j);
+        if (!aligned(dsts[j], 8)) return fail(AQUA_E_ALIGN, "destination %d is not 8-byte aligned", j);
+        wide = wide && aligned(dsts[j], 16);
+    }
+    size_t blocks = (bytes + COPY_BYTES_PER_BLOCK - 1) / COPY_BYTES_PER_BLOCK;
+    blocks = blocks < COPY_BLOCKS_MIN ? COPY_BLOCKS_MIN : (blocks > COPY_BLOCKS_MAX ? COPY_BLOCKS_MAX : blocks);
+    for (int first = 0; first < n_dst; first += COPY_FANOUT_MAX) {
+        CopyFanout f;
+        const int m = n_dst - first < COPY_FANOUT_MAX ? n_dst - first : COPY_FANOUT_MAX;
+        for (int j = 0; j < COPY_FANOUT_MAX; ++j) f.dst[j] = dsts[first + (j < m ? j : 0)];
+        const dim3 grid(static_cast<unsigned>(blocks), static_cast<unsigned>(m));
+        if (wide)
+            hipLaunchKernelGGL((copy_fanout_kernel<Word16>), grid, dim3(64), 0, static_cast<hipStream_t>(stream), f,
+                               static_cast<const Word16*>(src), bytes / 16);
+        else
+            hipLaunchKernelGGL((copy_fanout_kernel<unsigned long long>), grid, dim3(64), 0, static_cast<hipStream_t>(stream), f,
+                               static_cast<const unsigned long long*>(src), bytes / 8);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "aqua_copy_fanout_async launch");
+    }
+    return 0;
+}
+
+int aqua_copy_async(void* dst, const void* src, size_t bytes, int engine, void* stream)
+{
+    if (bytes == 0) return 0;
+    if (dst == nullptr || src == nullptr) return fail(AQUA_E_INVALID, "dst/src is NULL");
+    if (engine == AQUA_COPY_ENGINE_DMA) {
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyAsync (device to device)");
+    }
+    if (engine != AQUA_COPY_ENGINE_WAVES) return fail(AQUA_E_INVALID, "unknown copy engine %d", engine);
+    if (bytes % 8 != 0 || !aligned(dst, 8) || !aligned(src, 8)) return fail(AQUA_E_ALIGN, "aqua_copy_async moves whole 8-byte words");
+    size_t blocks = (bytes + COPY_BYTES_PER_BLOCK - 1) / COPY_BYTES_PER_BLOCK;
+    blocks = blocks < COPY_BLOCKS_MIN ? COPY_BLOCKS_MIN : (blocks > COPY_BLOCKS_MAX ? COPY_BLOCKS_MAX : blocks);
+    if (bytes % 16 == 0 && aligned(dst, 16) && aligned(src, 16))
+        hipLaunchKernelGGL((copy_words_kernel<Word16>), dim3(static_cast<unsigned>(blocks)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                           static_cast<Word16*>(dst), static_cast<const Word16*>(src), bytes / 16);
+    else
+        hipLaunchKernelGGL((copy_words_kernel<unsigned long long>), dim3(static_cast<unsigned>(blocks)), dim3(64), 0,
+                           static_cast<hipStream_t>(stream), static_cast<unsigned long long*>(dst),
+                           static_cast<const unsigned long long*>(src), bytes / 8);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "aqua_copy_async launch");
 }
 
 }  // extern "C"

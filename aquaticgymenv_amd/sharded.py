@@ -8,8 +8,10 @@ of the shards is bit-identical to a single-device run (tests/test_hip_parity.py:
 The only exchange is the episodic done mask: every rank contributes its bit-packed ballot words
 (uint64 per 64 worlds, 32 KiB per step at 262 144 worlds) and receives everybody's.  One process per
 GPU, torch.distributed; backend "nccl" is RCCL over xGMI on MI355X, "gloo" is used by the CPU tests.
-The gather runs on a side stream and is consumed late (it is not on the next step's dependency
-chain -- restarts are local), so the step stream never waits for it.
+The exchange runs on side streams and is consumed late (it is not on the next step's dependency
+chain -- restarts are local), so the step stream never waits for it.  Two transports (DoneMaskExchange):
+RCCL's all-gather, or peer copies into receive buffers mapped through hipIpcMemHandle -- no kernel on
+the compute units, which are exactly one round of step blocks at 262 144 worlds per GPU.
 """
 import numpy as np
 
@@ -28,15 +30,41 @@ def shard_range(total, world_size, rank):
     return offset, count
 
 
+class _DevicePointerArray(object):
+    """a device allocation the library owns (AquaIpcBuffer), shown to torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr, shape, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def ipc_block_offset(slot, sender, world, steps, words, itemsize=8):
+    """byte offset of `sender`'s [steps][words] block inside slot `slot` of a receive buffer [slots][world][steps][words]"""
+    if not (0 <= sender < world) or slot < 0:
+        raise ValueError("bad slot %d / sender %d of %d" % (slot, sender, world))
+    return ((slot * world + sender) * steps * words) * itemsize
+
+
 class DoneMaskExchange(object):
-    """All-gather of [steps][words] int64 done-mask blocks across the ranks of `group`.
+    """Every rank's [steps][words] int64 done-mask block delivered to every rank of `group`: gathered[slot] is
+    [world][steps][words].  words must be the same on every rank (pad the last shard).
 
-    words must be the same on every rank (pad the last shard); gathered shape is
-    [world][steps][words].  On CUDA/HIP tensors the collective is queued on a private side stream
-    behind an event of the producing stream; on CPU tensors (gloo) it runs synchronously.
-    """
+    kind="rccl" (default, what BASELINE.json's north_star names): torch.distributed.all_gather_into_tensor -- RCCL over
+        xGMI on device tensors, queued on a private side stream behind an event of the producing stream; gloo on CPU
+        tensors, synchronously.  RCCL's kernel runs on the compute units: one rank already pays 18-21 % of the step
+        stream for it (profiles/r02/exchange_overhead_one_rank.txt).
+    kind="ipc": no collective kernel.  Every rank owns a receive buffer (include/aqua_hip.h aqua_ipc_*), the ranks exchange
+        its 64-byte handle ONCE over the process group and map each other's buffers; a block is published as world - 1
+        asynchronous device-to-device copies (one side stream per peer, so the copies of a block use different links)
+        plus a local copy, all behind an event of the producing stream.  copy_engine: "waves" = a short kernel of
+        single-wavefront workgroups, "dma" = hipMemcpyAsync (the copy engines over xGMI: nothing on the compute units),
+        "auto" (default) = waves into the own buffer, dma into the peers'.  There is no per-block handshake:
+        a rank may publish at most `slots` blocks between two fence() calls, and what the OTHER ranks sent is complete in
+        gathered[slot] after the next fence() (finish() + barrier: bench.py's region boundary).
+    Either kind: the step stream never waits for the exchange, except before it overwrites a source buffer whose last
+    copy has not been read yet (wait_source) -- and no stream of the device ever waits for the step stream: the copies
+    are queued by a pump thread once the block's event has completed (see gather_async)."""
 
-    def __init__(self, steps, words, device, group=None, double_buffer=True):
+    def __init__(self, steps, words, device, group=None, double_buffer=True, kind="rccl", slots=None, copy_engine="auto"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -46,70 +74,251 @@ class DoneMaskExchange(object):
         self.rank = dist.get_rank(group) if self.collective else 0
         self.steps, self.words = int(steps), int(words)
         self.device = torch.device(device)
-        nbuf = 2 if double_buffer else 1
-        self.gathered = [torch.zeros((self.world, self.steps, self.words), dtype=torch.int64, device=self.device)
-                         for _ in range(nbuf)]
+        if kind not in ("rccl", "ipc"):
+            raise ValueError("kind must be 'rccl' or 'ipc'")
+        self.kind = kind
+        if copy_engine not in ("auto", "waves", "dma"):
+            raise ValueError("copy_engine must be 'auto', 'waves' or 'dma'")
+        self.copy_engine = copy_engine
+        nbuf = int(slots) if slots is not None else (2 if double_buffer else 1)
+        if nbuf < 1:
+            raise ValueError("slots must be >= 1")
+        self.slots = nbuf
         self._slot = 0
         self._pending = [None] * nbuf
-        self._source_busy = {}            # source_id -> event after which the caller may overwrite that source
-        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._source_busy = {}            # source_id -> the job that reads that source
+        self._since_fence = 0
+        self._ipc = None
+        self._pump = None
+        if kind == "ipc":
+            self._setup_ipc()
+        else:
+            self.gathered = [torch.zeros((self.world, self.steps, self.words), dtype=torch.int64, device=self.device)
+                             for _ in range(nbuf)]
+            self._side = [torch.cuda.Stream(device=self.device)] if self.device.type == "cuda" else []
+
+    # ------------------------------------------------------------------ kind="ipc"
+    def _setup_ipc(self):
+        import ctypes
+        from . import _capi
+        torch, dist = self.torch, self.dist
+        if self.device.type != "cuda":
+            raise RuntimeError("DoneMaskExchange(kind='ipc') moves device buffers between GPU processes: device must be a HIP device")
+        lib = _capi.lib
+        nbytes = self.slots * self.world * self.steps * self.words * 8
+        with torch.cuda.device(self.device):
+            buf = ctypes.c_void_p()
+            _capi.check(lib.aqua_ipc_buffer_create(nbytes, ctypes.byref(buf)), "aqua_ipc_buffer_create")
+            handle = ctypes.create_string_buffer(_capi.IPC_HANDLE_BYTES)
+            _capi.check(lib.aqua_ipc_buffer_handle(buf, handle), "aqua_ipc_buffer_handle")
+            base = int(lib.aqua_ipc_buffer_ptr(buf))
+            handles = [None] * self.world
+            if self.collective:
+                dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+            else:
+                handles[0] = bytes(handle.raw)
+            peers = [None] * self.world
+            peers[self.rank] = base
+            for r in range(self.world):
+                if r != self.rank:
+                    p = ctypes.c_void_p()
+                    _capi.check(lib.aqua_ipc_open(handles[r], ctypes.byref(p)), "aqua_ipc_open (rank %d)" % r)
+                    peers[r] = int(p.value)
+            whole = torch.as_tensor(_DevicePointerArray(base, (self.slots, self.world, self.steps, self.words)), device=self.device)
+        self._ipc = {"lib": lib, "buf": buf, "peers": peers, "whole": whole}
+        self.gathered = [whole[s] for s in range(self.slots)]
+        # one side stream per destination (the own slot included): the copies of one block run side by side
+        self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.world)]
+        if self.collective:
+            dist.barrier(group=self.group)        # everybody has mapped everybody before the first copy
+
+    def close(self):
+        """unmap the peers' buffers and free the own one (after a fence(): nobody may still be writing into it)"""
+        self.finish()
+        self.stop()
+        if self._ipc is None:
+            return
+        if self.collective:
+            self.dist.barrier(group=self.group)
+        lib, ipc = self._ipc["lib"], self._ipc
+        self.gathered = []
+        ipc["whole"] = None
+        for r, p in enumerate(ipc["peers"]):
+            if r != self.rank and p:
+                lib.aqua_ipc_close(p)
+        lib.aqua_ipc_buffer_destroy(ipc["buf"])
+        self._ipc = None
+
+    # ------------------------------------------------------------------ both kinds
+    def _job_events(self, job):
+        """host: until the pump has queued the job's copies (the GPU has reached the block's last step); then its events"""
+        if job is None:
+            return ()
+        job.submitted.wait()
+        if job.error is not None:
+            raise job.error
+        return job.events
+
+    def _wait_events(self, events):
+        if not events:
+            return
+        cur = self.torch.cuda.current_stream(self.device)
+        for ev in events:
+            if not ev.query():            # (a wait for a finished event still costs the stream a barrier packet)
+                cur.wait_event(ev)
 
     def wait_source(self, source_id):
-        """Make the current stream wait until the gather that last READ the caller's buffer `source_id` is done
+        """Make the current stream wait until the exchange that last READ the caller's buffer `source_id` is done
         (call before the kernels that overwrite that buffer)."""
-        ev = self._source_busy.pop(source_id, None)
-        if ev is not None:
-            self.torch.cuda.current_stream(self.device).wait_event(ev)
+        self._wait_events(self._job_events(self._source_busy.pop(source_id, None)))
 
-    def gather_async(self, local_bits, source_id=None):
-        """Queue the all-gather of local_bits ([steps][words] int64, contiguous).  Returns the slot index
-        whose `gathered[slot]` holds the result after wait(slot)."""
+    def gather_async(self, local_bits, source_id=None, final=False):
+        """Queue the exchange of local_bits ([steps][words] int64, contiguous).  Returns the slot index whose
+        `gathered[slot]` holds the result: after wait(slot) for kind="rccl", after the next fence() for kind="ipc".
+        final=True: nothing follows this block on the producing stream before the caller drains it (the last block of a
+        timed region).  kind="ipc" then delivers it with ONE fan-out launch on the producing stream itself, in stream
+        order behind the block's last step: no host round trip, no second stream, no thread hand-off -- which is what
+        a 100-microsecond region can afford."""
         torch, dist = self.torch, self.dist
         if tuple(local_bits.shape) != (self.steps, self.words) or local_bits.dtype != torch.int64 \
                 or not local_bits.is_contiguous():
             raise ValueError("local_bits must be a contiguous int64 [%d][%d] tensor" % (self.steps, self.words))
+        if self.kind == "ipc" and self._since_fence >= self.slots:
+            raise RuntimeError("DoneMaskExchange(kind='ipc'): %d blocks published since the last fence(), the receive "
+                               "buffers hold %d" % (self._since_fence, self.slots))
         slot = self._slot
-        self._slot = (self._slot + 1) % len(self.gathered)
+        self._slot = (self._slot + 1) % self.slots
+        self._since_fence += 1
         self.wait(slot)                       # the buffer we are about to overwrite must have been consumed
         out = self.gathered[slot]
-        if not self.collective:
-            if self._side is not None:
-                self._side.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._side):
-                    out[0].copy_(local_bits, non_blocking=True)
-                    local_bits.record_stream(self._side)
-                self._pending[slot] = self._side.record_event()
-                if source_id is not None:
-                    self._source_busy[source_id] = self._pending[slot]
+        if not self._side:                    # CPU tensors (gloo): synchronously
+            if self.collective:
+                dist.all_gather_into_tensor(out.view(-1), local_bits.view(-1), group=self.group)
             else:
                 out[0].copy_(local_bits)
             return slot
-        if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self._side):
-                dist.all_gather_into_tensor(out.view(-1), local_bits.view(-1), group=self.group)
-                local_bits.record_stream(self._side)
-            self._pending[slot] = self._side.record_event()
+        # Device tensors.  The block's copies go to side streams, but NOT behind a device-side wait: a stream that sits on
+        # an unfinished event of the step stream costs every step launch of the other stream ~1 us for as long as it waits
+        # (profiles/r03/exchange_pieces.txt: 5.02 -> 6.02 us per step with nothing but that wait -- which is what made
+        # every transport, RCCL included, look equally expensive).  The wait happens on the HOST instead: a pump thread
+        # sleeps in hipEventSynchronize and queues the copies once the block is complete.
+        if self.kind == "ipc" and final:
+            import ctypes
+            from . import _capi
+            cur = torch.cuda.current_stream(self.device)
+            offset = ipc_block_offset(slot, self.rank, self.world, self.steps, self.words)
+            dsts = (ctypes.c_void_p * self.world)(*[p + offset for p in self._ipc["peers"]])
+            with torch.cuda.device(self.device):
+                _capi.check(self._ipc["lib"].aqua_copy_fanout_async(dsts, self.world, local_bits.data_ptr(),
+                                                                    self.steps * self.words * 8, ctypes.c_void_p(cur.cuda_stream)),
+                            "aqua_copy_fanout_async")
+            job = _ExchangeJob(None)
+            job.events.append(cur.record_event())
+            job.submitted.set()
+            self._pending[slot] = job
             if source_id is not None:
-                self._source_busy[source_id] = self._pending[slot]
+                self._source_busy[source_id] = job
+            return slot
+        job = _ExchangeJob(torch.cuda.current_stream(self.device).record_event())
+        if self.kind == "ipc":
+            import ctypes
+            from . import _capi
+            lib, peers = self._ipc["lib"], self._ipc["peers"]
+            nbytes = self.steps * self.words * 8
+
+            def submit():
+                for r in range(self.world):
+                    st = self._side[r]
+                    dst = peers[r] + ipc_block_offset(slot, self.rank, self.world, self.steps, self.words)
+                    dma = self.copy_engine == "dma" or (self.copy_engine == "auto" and r != self.rank)
+                    _capi.check(lib.aqua_copy_async(dst, local_bits.data_ptr(), nbytes,
+                                                    _capi.COPY_ENGINE_DMA if dma else _capi.COPY_ENGINE_WAVES,
+                                                    ctypes.c_void_p(st.cuda_stream)), "aqua_copy_async (to rank %d)" % r)
+                    job.events.append(st.record_event())
         else:
-            dist.all_gather_into_tensor(out.view(-1), local_bits.view(-1), group=self.group)
+            side = self._side[0]
+
+            def submit():
+                with torch.cuda.stream(side):
+                    if self.collective:
+                        dist.all_gather_into_tensor(out.view(-1), local_bits.view(-1), group=self.group)
+                    else:
+                        out[0].copy_(local_bits, non_blocking=True)
+                job.events.append(side.record_event())
+        job.submit = submit
+        job.keep = local_bits                  # the source stays alive until its copies have been queued
+        self._pump_put(job)
+        self._pending[slot] = job
+        if source_id is not None:
+            self._source_busy[source_id] = job
         return slot
 
+    def _pump_put(self, job):
+        import queue
+        import threading
+        if self._pump is None:
+            self._jobs = queue.Queue()
+
+            def pump():
+                self.torch.cuda.set_device(self.device)
+                while True:
+                    j = self._jobs.get()
+                    if j is None:
+                        return
+                    try:
+                        j.ready.synchronize()      # host-side wait (hipEventSynchronize; the GIL is released)
+                        j.submit()
+                    except BaseException as exc:   # handed to whoever waits for the job
+                        j.error = exc
+                    j.submitted.set()
+            self._pump = threading.Thread(target=pump, name="done-mask-exchange-pump", daemon=True)
+            self._pump.start()
+        self._jobs.put(job)
+
     def wait(self, slot=None):
-        """Make the current stream wait for the gather in `slot` (all slots when None)."""
-        slots = range(len(self.gathered)) if slot is None else (slot,)
+        """Make the current stream wait for what THIS rank queued for `slot` (all slots when None)."""
+        slots = range(self.slots) if slot is None else (slot,)
         for s in slots:
-            ev = self._pending[s]
-            if ev is not None:
-                self.torch.cuda.current_stream(self.device).wait_event(ev)
-                self._pending[s] = None
+            self._wait_events(self._job_events(self._pending[s]))
+            self._pending[s] = None
 
     def finish(self):
-        """Host-side completion of everything queued (end of a timed region)."""
+        """Host-side completion of everything this rank queued (end of a timed region)."""
         self.wait()
-        if self._side is not None:
-            self._side.synchronize()
+        for job in list(self._source_busy.values()):
+            self._job_events(job)
+        for st in self._side:
+            st.synchronize()
+
+    def fence(self):
+        """finish() + a barrier over the group: every block published before it, by ANY rank, is in place in gathered[];
+        the slots may be published into again."""
+        self.finish()
+        if self.collective:
+            self.dist.barrier(group=self.group)
+        self._since_fence = 0
+
+    def note_fence(self):
+        """the caller has run finish() and a barrier of its own (bench.py's region boundary)"""
+        self._since_fence = 0
+
+    def stop(self):
+        """end the pump thread (after finish())"""
+        if self._pump is not None:
+            self._jobs.put(None)
+            self._pump.join(timeout=10)
+            self._pump = None
+
+
+class _ExchangeJob(object):
+    """one published block: `ready` (event of the producing stream), what to queue once it has completed, and the events
+    of what was queued"""
+
+    def __init__(self, ready):
+        import threading
+        self.ready, self.submit, self.keep = ready, None, None
+        self.events, self.error = [], None
+        self.submitted = threading.Event()
 
 
 def unpack_done_words(words, count):

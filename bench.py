@@ -4,12 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the second form itself, as a fresh child process,
+before this process has made any HIP call, relays rank 0's line and exits with the children's status.
 
 A "step" is ONE batched step (one launch of the fused step kernel) over one batch of worlds.
 Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quoted on):
 262 144 worlds, discrete uint8 actions (pre-generated, i.i.d. uniform), 4 circle + 4 rectangle
 obstacles, waves on, Philox noise, auto-reset on.  N > 1: the same batch PER GPU (weak scaling),
-range-partitioned global world indices, done-mask all-gather over RCCL on a side stream.
+range-partitioned global world indices, the done mask exchanged on side streams (peer copies through hipIpcMemHandle
+when the ranks can map each other's buffers, else RCCL's all-gather).
 
 Protocol: W untimed warm-up steps, then REGIONS (5) timed regions of EXACTLY K
 steps each, every region bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's clock
@@ -17,7 +20,8 @@ stops when ITS queue has drained, steps and done-mask gathers; the barrier follo
 with MAX over the ranks; the MEDIAN region is the one reported (`value`, `ms_per_step`; all five are
 listed under `regions_ms`).  Steps are queued as replays of captured HIP graphs of min(CHUNK, K) steps
 (+ one graph for the remainder), so that any K >= 1 and W >= 0 runs the same way.  Inputs are resident
-in HBM before the timed regions.  Rank 0 prints ONE JSON line.
+in HBM before the timed regions.  `roofline` comes from HIP events recorded on the launch stream around each region's
+launches.  Rank 0 prints ONE JSON line.
 
 The CPU baselines (`cpu_baseline*`, oracle/ = test infrastructure, never the product path) run BEFORE
 the process touches the GPU: their worker processes are started with fork+exec, which must not happen
@@ -58,7 +62,20 @@ def parse(argv=None):
     ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="run the done-mask exchange (side stream, double buffer) even on one GPU: rehearsal of the N > 1 path")
+                    help="run the done-mask exchange (side streams) even on one GPU: rehearsal of the N > 1 path")
+    ap.add_argument("--exchange", choices=("auto", "ipc", "rccl"), default="auto",
+                    help="transport of the done-mask exchange: peer copies into IPC-mapped receive buffers (no kernel on the "
+                         "compute units), RCCL's all-gather, or auto = ipc when the ranks can map each other, else rccl")
+    ap.add_argument("--copy-engine", choices=("auto", "waves", "dma"), default="auto",
+                    help="--exchange ipc: copy by single-wavefront workgroups, by hipMemcpyAsync, or auto = wavefronts into "
+                         "the own buffer and hipMemcpyAsync (the copy engines) into the other GPUs' buffers")
+    ap.add_argument("--ranks-on-one-gpu", action="store_true",
+                    help="rehearsal on a 1-GPU box: all --gpus ranks share cuda:0, gloo carries the barriers (RCCL refuses two "
+                         "ranks on one device), the done mask moves by IPC peer copies.  Checks the N > 1 path on device "
+                         "tensors; its timings mean nothing")
+    ap.add_argument("--graph-node-events", action="store_true",
+                    help="diagnostic: a region that is one graph ALSO carries event-record nodes at its head and tail "
+                         "(round 2's clock), reported beside the stream events as roofline.launch_us_graph_nodes_regions")
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel (separate line)")
     ap.add_argument("--per-world-tables", action="store_true",
                     help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
@@ -152,19 +169,30 @@ class StepRunner(object):
             self.timing_error = "%s: %s" % (type(exc).__name__, exc)
             return None
 
-    def run(self, n_steps):
-        """exactly n_steps steps; returns the segments it queued"""
+    def run(self, n_steps, after_last_launch=None, before_first_launch=None):
+        """exactly n_steps steps; returns the segments it queued.  before_first_launch() is called right ahead of the
+        region's first step launch, after_last_launch() right behind its last one and ahead of the exchange of its last
+        block: where bench.py records its HIP events, so that the exchange's host-side bookkeeping (on an idle stream an
+        event is stamped at once) is not inside the interval"""
         segs = self.plan(n_steps)
-        for buf, row0, s, gather_after in segs:
+        for i, (buf, row0, s, gather_after) in enumerate(segs):
             if self.exchange is not None and row0 == 0:
                 self.exchange.wait_source(buf)
+            if before_first_launch is not None and i == 0:
+                before_first_launch()
             if self.use_graph:
                 self.graphs[(buf, row0, s)].launch()
             else:
                 self.env.rollout(s, actions=self.actions, keep_all=False, done_history=self.hist[buf][row0:row0 + s])
+            if after_last_launch is not None and i == len(segs) - 1:
+                after_last_launch()
             if self.exchange is not None and gather_after:
-                self.exchange.gather_async(self.hist[buf], source_id=buf)
+                self.exchange.gather_async(self.hist[buf], source_id=buf, final=i == len(segs) - 1)
             self.steps_run += s
+        if not segs:
+            for hook in (before_first_launch, after_last_launch):
+                if hook is not None:
+                    hook()
         return segs
 
     @property
@@ -184,8 +212,16 @@ def episodes_ended(hist, segs, np):
     for buf, row0, s, _ in segs:
         words = hist[buf][row0:row0 + s]
         words = words.cpu().numpy() if hasattr(words, "cpu") else np.asarray(words)
-        total += int(np.bitwise_count(np.ascontiguousarray(words).view(np.uint64)).sum())
+        total += popcount_words(np.ascontiguousarray(words), np)
     return total
+
+
+def popcount_words(words, np):
+    """set bits of an array of 64-bit words (np.bitwise_count needs numpy >= 2)"""
+    w = np.ascontiguousarray(words).view(np.uint64)
+    if hasattr(np, "bitwise_count"):
+        return int(np.bitwise_count(w).sum())
+    return int(np.unpackbits(w.view(np.uint8)).sum())
 
 
 # ------------------------------------------------------------------ CPU baselines (oracle/: the checker, timed beside the GPU)
@@ -286,16 +322,93 @@ def cpu_baselines(args, obstacles):
     return allc, one, c
 
 
+# ------------------------------------------------------------------ self-launch of the N > 1 form (tests/test_bench_logic.py)
+def needs_self_launch(gpus, environ):
+    """`bench.py --gpus N` with N > 1 was started bare (no launcher set WORLD_SIZE / RANK): it must start the ranks itself"""
+    return gpus > 1 and "RANK" not in environ and int(environ.get("WORLD_SIZE", "1")) == 1
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_command(gpus, argv, port, python=None, script=None):
+    """the driver's own N > 1 command line around the arguments this process was given"""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv, device_count=None, run=None):
+    """Start the ranks as a FRESH child process (never a re-exec: this process may not replace itself once anything has
+    touched the GPU, and the children must initialise HIP themselves), relay rank 0's JSON line, return the children's
+    status.  Refuses, with a message and a non-zero status, when the box has fewer GPUs than ranks."""
+    import subprocess
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count()       # does not initialise HIP on this image
+    if device_count < args.gpus and not args.ranks_on_one_gpu:
+        sys.stderr.write("bench.py --gpus %d: this box shows %d GPU(s); one rank per GPU is the only supported layout "
+                         "(--ranks-on-one-gpu rehearses the path on one device, without meaningful timings)\n"
+                         % (args.gpus, device_count))
+        return 2
+    if device_count < 1:
+        sys.stderr.write("bench.py: no GPU visible\n")
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launch_command(args.gpus, argv, free_port())
+    if run is not None:
+        return run(cmd, env)
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                            # rank 0's line goes to stdout, everything else to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+# ------------------------------------------------------------------ the done-mask exchange of this run
+def exchange_blocks(n_steps, chunk, block_rows):
+    """done-mask blocks a region of n_steps publishes (kind="ipc" needs that many receive slots between two fences)"""
+    return sum(1 for seg in plan_region(n_steps, chunk, block_rows) if seg[3])
+
+
+def make_exchange(kind, block_rows, words, dev, slots, rank, world, torch, DoneMaskExchange, copy_engine="auto"):
+    """-> (exchange, kind used, note).  kind "auto": peer copies through IPC-mapped buffers when every rank can map every
+    other rank's buffer AND a probe block arrives intact everywhere, else RCCL's all-gather."""
+    note = None
+    if kind in ("auto", "ipc"):
+        try:
+            ex = DoneMaskExchange(block_rows, words, dev, kind="ipc", slots=max(2, slots), copy_engine=copy_engine)
+            probe = (torch.arange(block_rows * words, dtype=torch.int64, device=dev).reshape(block_rows, words)
+                     + (rank + 1) * 1000003)
+            slot = ex.gather_async(probe)
+            ex.fence()
+            for r in range(world):
+                expect = probe - (rank + 1) * 1000003 + (r + 1) * 1000003
+                if not torch.equal(ex.gathered[slot][r], expect):
+                    raise RuntimeError("probe block of rank %d did not arrive intact" % r)
+            return ex, "ipc", None
+        except Exception as exc:
+            if kind == "ipc":
+                raise
+            note = "ipc unavailable (%s: %s): RCCL all-gather" % (type(exc).__name__, exc)
+    return DoneMaskExchange(block_rows, words, dev, kind="rccl"), "rccl", note
+
+
 # ------------------------------------------------------------------ main
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
+    if needs_self_launch(args.gpus, os.environ):
+        sys.exit(self_launch(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
         args.gpus = world
 
     from aquaticgymenv_amd import presets
@@ -310,12 +423,24 @@ def main(argv=None):
     from aquaticgymenv_amd.batched import BatchedAqua
     from aquaticgymenv_amd.sharded import DoneMaskExchange
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    one_gpu = args.ranks_on_one_gpu
+    dev = torch.device("cuda", 0 if one_gpu else local_rank)
+    torch.cuda.set_device(dev)
     distributed = world > 1 or "RANK" in os.environ
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")              # RCCL refuses two ranks on one device; gloo carries the barriers
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    ranks_seen = dist.get_world_size() if distributed else 1
+    if distributed:
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, "rank %d: cuda:%d %s" % (rank, dev.index, torch.cuda.get_device_name(dev)))
+    else:
+        devices = ["rank 0: cuda:%d %s" % (dev.index, torch.cuda.get_device_name(dev))]
+    launch_stream = torch.cuda.Stream(device=dev)        # the step kernels' stream; the HIP events are recorded on it
+    torch.cuda.set_stream(launch_stream)
 
     n = args.envs
     env = BatchedAqua(n, obstacles=obstacles, continuous=args.continuous, seed=0, env_offset=rank * n,
@@ -332,10 +457,14 @@ def main(argv=None):
     # 20-step region must not ship a 500-row buffer through RCCL)
     block_rows = max(chunk, min(GATHER_EVERY * CHUNK, args.steps))
     hist = [torch.zeros((block_rows, words), dtype=torch.int64, device=dev) for _ in range(2)]
-    exchange = DoneMaskExchange(block_rows, words, dev) if (world > 1 or args.force_exchange) else None
+    exchange, exchange_kind, exchange_note = None, None, None
+    if world > 1 or args.force_exchange:
+        slots = max(exchange_blocks(args.warmup, chunk, block_rows), exchange_blocks(args.steps, chunk, block_rows), 1)
+        exchange, exchange_kind, exchange_note = make_exchange("ipc" if one_gpu else args.exchange, block_rows, words, dev, slots,
+                                                               rank, ranks_seen, torch, DoneMaskExchange, args.copy_engine)
     runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk)
     runner.prepare(args.warmup)
-    runner.prepare(args.steps, timing=True)
+    runner.prepare(args.steps, timing=args.graph_node_events)
 
     def drain():
         """everything this rank queued has run: the steps, and the done-mask gathers behind them on the side stream"""
@@ -346,37 +475,34 @@ def main(argv=None):
     def rendezvous():
         """barrier + synchronize: the closing bracket of one region is the opening bracket of the next.  The clock of a
         region stops at this rank's own drain() -- the region's time is the MAX over the ranks of that, which is when the
-        slowest rank was done; the barrier's own latency is not part of any region"""
+        slowest rank was done; the barrier's own latency is not part of any region.  It is also the fence of the
+        done-mask exchange: every rank has drained, so every block published in the region is in place everywhere"""
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
+        if exchange is not None:
+            exchange.note_fence()
 
     runner.run(args.warmup)
     drain()
     rendezvous()
     x_before = float(env.state[0, :n].double().sum().item())
-    walls, events, graph_ms, segs = [], [], [], []
-    # a region that is ONE timed graph carries its own event-record nodes: no stream events (two host calls less inside
-    # the wall-clock bracket of a 100-microsecond region)
-    in_graph = runner.region_is_timed_graph(args.steps)
+    walls, events, node_ms, segs = [], [], [], []
     for _ in range(args.regions):
-        if not in_graph:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # HIP events on the stream the step kernels are launched on, around the region's launches (the contract's
+        # `roofline` clock).  Round 2 timed a one-graph region with event-record NODES inside the graph instead: measured
+        # side by side (profiles/r03/k20_event_methods.txt) the two nodes add ~7 us of their own to a 100-us graph
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        if not in_graph:
-            e0.record()
-        segs = runner.run(args.steps)
-        if not in_graph:
-            e1.record()
+        segs = runner.run(args.steps, before_first_launch=lambda: e0.record(launch_stream),
+                          after_last_launch=lambda: e1.record(launch_stream))
         drain()
         walls.append(time.perf_counter() - t0)
         rendezvous()
-        events.append(None if in_graph else e0.elapsed_time(e1))   # ms, on the stream the step kernels are launched on
-        graph_ms.append(runner.region_graph_ms(segs) if in_graph else None)
-    if in_graph and not all(g is not None and g > 0.0 for g in graph_ms):
-        raise RuntimeError("the graph's event-record nodes returned no time (%s)" % runner.timing_error)
+        events.append(e0.elapsed_time(e1))               # ms
+        node_ms.append(runner.region_graph_ms(segs) if args.graph_node_events else None)
     if distributed:
-        tmax = torch.tensor(walls, dtype=torch.float64, device=dev)
+        tmax = torch.tensor(walls, dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         walls = [float(v) for v in tmax.cpu()]
 
@@ -400,7 +526,7 @@ def main(argv=None):
         # the step kernel is the only kernel in the timed stream: its average launch period on the launch stream
         # (HIP events around the region: inter-kernel boundaries and the event-to-first-kernel gap included, so
         # this is an upper bound of the kernel's own duration); median over the regions
-        launch_s = statistics.median(graph_ms if in_graph else events) * 1e-3 / args.steps
+        launch_s = statistics.median(events) * 1e-3 / args.steps
         achieved = a_bytes * n / launch_s / 1e9
         traffic, traffic_src = committed_traffic(n, args)
         result = {
@@ -416,17 +542,22 @@ def main(argv=None):
                           "HIP graphs" if runner.use_graph else "eager launch loops", chunk),
                        "baseline_config": "configs[3]" if args.continuous else ("configs[1]-like" if args.no_obstacles else "configs[2]"),
                        "worlds_per_gpu": n, "global_worlds": world * n, "parallelism": "range-partition x%d" % world,
-                       "launch": runner.launch, "done_mask_exchange": exchange is not None},
+                       "launch": runner.launch, "done_mask_exchange": exchange is not None,
+                       "done_mask_exchange_kind": exchange_kind, "done_mask_exchange_note": exchange_note,
+                       "done_mask_copy_engine": args.copy_engine if exchange_kind == "ipc" else None,
+                       "ranks_seen": ranks_seen, "devices": devices,
+                       "process_group": (("gloo (ranks share cuda:0: rehearsal, timings meaningless)" if one_gpu else "nccl (RCCL)")
+                                         if distributed else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
-                         "launch_us_regions": [(g if in_graph else e) * 1e3 / args.steps for g, e in zip(graph_ms, events)],
-                         "launch_us_events": "graph nodes" if in_graph else "stream",
-                         "graph_timing_error": runner.timing_error,
+                         "launch_us_regions": [e * 1e3 / args.steps for e in events],
+                         "launch_us_events": "stream",
+                         "launch_us_graph_nodes_regions": ([g * 1e3 / args.steps if g else None for g in node_ms]
+                                                           if args.graph_node_events else None),
                          "note": "launch_us = HIP-event time of a timed region / its launches, median region, inter-kernel "
-                                 "boundaries included.  'graph nodes': the region is ONE graph whose first and last node "
-                                 "record the events (no host launch latency inside the interval); 'stream': events recorded "
-                                 "on the launch stream around the region's graph launches.  Kernel-only duration: profiles/"},
+                                 "boundaries included; the events are recorded on the launch stream around the region's "
+                                 "graph launches.  Kernel-only duration: profiles/"},
             "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended},
         }
         if cpu is not None:

@@ -11,7 +11,7 @@
  *  - every DEVICE buffer is owned by the caller; the library borrows the pointers for the duration
  *    of the call (asynchronously: until the work queued on `stream` has run), allocates nothing,
  *    frees nothing and keeps no pointer afterwards.  The only objects the library owns are the
- *    AquaGraph handles returned by aqua_graph_end().
+ *    AquaGraph handles returned by aqua_graph_end(), the AquaEvent handles and the AquaIpcBuffer receive buffers.
  *  - launches are asynchronous on `stream`; no entry point synchronises the device, so all of
  *    them may be captured into a HIP graph.
  *  - return value: 0 = ok; > 0 = hipError_t; < 0 = AQUA_E_*.  aqua_last_error() returns a
@@ -35,9 +35,10 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 4   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
+#define AQUA_ABI_VERSION 5   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
                                 3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed;
-                                4: aqua_rollout_tables_fused_f32 */
+                                4: aqua_rollout_tables_fused_f32;
+                                5: aqua_ipc_*, aqua_copy_async (done-mask exchange by peer copies) */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
@@ -249,6 +250,37 @@ int aqua_event_record(AquaEvent* e, void* stream);
 int aqua_graph_end_timed(void* stream, AquaGraph** out, AquaEvent* start, AquaEvent* stop);
 int aqua_event_elapsed_ms(AquaEvent* start, AquaEvent* stop, float* ms);
 int aqua_event_destroy(AquaEvent* e);
+
+/*
+ * Done-mask exchange without a collective kernel (peer writes through hipIpcMemHandle).
+ * The one exchange of the sharded path is the episodic done mask (32 KiB of ballot words per step and GPU).  RCCL's
+ * all-gather runs on the compute units and takes them from the step kernels (one rank: 5.07 -> 6.15 us per step); a
+ * device-to-device copy does not.  So every rank owns a receive buffer that the other ranks of the node map and
+ * write into with asynchronous copies over xGMI:
+ *   aqua_ipc_buffer_create/ptr/handle/destroy   the receive buffer (the one device allocation the library makes: it has to
+ *                                               be an allocation of its own to be exported) and its 64-byte handle, which
+ *                                               the host side hands to the other ranks over its process group;
+ *   aqua_ipc_open / aqua_ipc_close              map / unmap another rank's buffer (hipIpcOpenMemHandle, lazy peer access);
+ *   aqua_copy_async                             device-to-device copy on `stream` (the side streams of aquaticgymenv_amd/
+ *                                               sharded.py DoneMaskExchange(kind="ipc")): AQUA_COPY_ENGINE_WAVES = eight
+ *                                               single-wavefront workgroups (whole 8-byte words; they fit beside the step
+ *                                               kernel's one round of blocks), AQUA_COPY_ENGINE_DMA = hipMemcpyAsync.
+ * The replaced reference interface is none: the reference is one process, one env object (main/testing/__init__.py:17-36).
+ */
+#define AQUA_IPC_HANDLE_BYTES 64
+typedef struct AquaIpcBuffer AquaIpcBuffer;
+int aqua_ipc_buffer_create(size_t bytes, AquaIpcBuffer** out);
+void* aqua_ipc_buffer_ptr(AquaIpcBuffer* b);
+int aqua_ipc_buffer_handle(AquaIpcBuffer* b, unsigned char handle[AQUA_IPC_HANDLE_BYTES]);
+int aqua_ipc_buffer_destroy(AquaIpcBuffer* b);
+int aqua_ipc_open(const unsigned char handle[AQUA_IPC_HANDLE_BYTES], void** peer_ptr);
+int aqua_ipc_close(void* peer_ptr);
+#define AQUA_COPY_ENGINE_WAVES 0
+#define AQUA_COPY_ENGINE_DMA   1
+int aqua_copy_async(void* dst, const void* src, size_t bytes, int engine, void* stream);
+/* the same bytes into n_dst buffers with ONE launch (wavefronts; blockIdx.y = destination): the last block of a region,
+ * queued in stream order right behind the region's last step */
+int aqua_copy_fanout_async(void* const* dsts, int n_dst, const void* src, size_t bytes, void* stream);
 
 /* the float32 constants the kernels use for the three discrete actions (aqua.py:33-42 folded through
  * aqua.py:159-170): out = h[3] (w/2), w[3], chord[3]; for tests. */

@@ -47,8 +47,9 @@ class StubExchange(object):
     def wait_source(self, buf):
         self.log.append(("wait", buf))
 
-    def gather_async(self, block, source_id=None):
+    def gather_async(self, block, source_id=None, final=False):
         self.log.append(("gather", source_id))
+        self.finals = getattr(self, "finals", []) + [final]
 
 
 def _hist(rows=bench.CHUNK * bench.GATHER_EVERY, words=4):
@@ -115,10 +116,13 @@ def test_runner_exchange_handoffs():
     r.prepare(1234)
     r.run(1234)          # 500 (buf 0) + 500 (buf 1) + 234 (buf 0)
     assert ex.log == [("wait", 0), ("gather", 0), ("wait", 1), ("gather", 1), ("wait", 0), ("gather", 0)]
+    assert ex.finals == [False, False, True]          # only the region's last block is published in stream order
     ex.log.clear()
+    closing = []
     r.prepare(20)
-    r.run(20)
-    assert ex.log == [("wait", 0), ("gather", 0)]
+    r.run(20, after_last_launch=lambda: closing.append(list(ex.log)))
+    assert ex.log == [("wait", 0), ("gather", 0)] and ex.finals[-1] is True
+    assert closing == [[("wait", 0)]]                 # the closing event goes in behind the launch, ahead of the exchange
 
 
 def test_median_pick():
@@ -142,3 +146,67 @@ def test_traffic_is_null_without_a_matching_build(monkeypatch):
     monkeypatch.setattr(bench, "library_tag", lambda: "0" * 16)
     traffic, src = bench.committed_traffic(262144, args)
     assert traffic is None and isinstance(src, str) and src
+
+
+# ------------------------------------------------------------------ the N > 1 entry launches itself (round 2: `bench.py --gpus N` sys.exit()ed)
+class _Args(object):
+    def __init__(self, gpus, ranks_on_one_gpu=False):
+        self.gpus, self.ranks_on_one_gpu = gpus, ranks_on_one_gpu
+
+
+def test_self_launch_is_needed_only_for_a_bare_multi_gpu_command():
+    assert bench.needs_self_launch(2, {})
+    assert bench.needs_self_launch(8, {"WORLD_SIZE": "1"})
+    assert not bench.needs_self_launch(1, {})
+    assert not bench.needs_self_launch(2, {"RANK": "0", "WORLD_SIZE": "2"})     # torch.distributed.run is around it
+    assert not bench.needs_self_launch(2, {"WORLD_SIZE": "2"})
+
+
+def test_launch_command_is_the_drivers_own():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], 29511, python="py", script="bench.py")
+    assert cmd == ["py", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                   "--master-port", "29511", "bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"]
+
+
+def test_self_launch_refuses_more_ranks_than_gpus(capsys):
+    ran = []
+    rc = bench.self_launch(_Args(2), ["--gpus", "2"], device_count=1, run=lambda cmd, env: ran.append(cmd) or 0)
+    assert rc != 0 and not ran, "must fail before starting anything"
+    assert "--gpus 2" in capsys.readouterr().err
+    assert bench.self_launch(_Args(2), ["--gpus", "2"], device_count=0, run=lambda cmd, env: 0) != 0
+
+
+def test_self_launch_starts_a_fresh_child_and_returns_its_status():
+    seen = {}
+
+    def run(cmd, env):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    rc = bench.self_launch(_Args(2), ["--gpus", "2", "--steps", "3"], device_count=8, run=run)
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the rehearsal layout is allowed on a 1-GPU box
+    assert bench.self_launch(_Args(2, ranks_on_one_gpu=True), ["--gpus", "2", "--ranks-on-one-gpu"], device_count=1, run=run) == 7
+
+
+def test_exchange_blocks_counts_the_blocks_of_a_region():
+    assert bench.exchange_blocks(20, 20, 20) == 1
+    assert bench.exchange_blocks(2000, 100, 500) == 4
+    assert bench.exchange_blocks(230, 100, 230) == 1
+    assert bench.exchange_blocks(0, 100, 500) == 0
+    assert bench.exchange_blocks(501, 100, 500) == 2
+
+
+def test_popcount_without_numpy2(monkeypatch):
+    w = np.array([0, 1, 3, 2 ** 63, 2 ** 64 - 1], dtype=np.uint64)
+    assert bench.popcount_words(w, np) == 0 + 1 + 2 + 1 + 64
+
+    class OldNumpy(object):
+        def __getattr__(self, name):
+            if name == "bitwise_count":
+                raise AttributeError(name)
+            return getattr(np, name)
+    assert bench.popcount_words(w.view(np.int64), OldNumpy()) == 68

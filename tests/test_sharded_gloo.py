@@ -166,3 +166,25 @@ def test_exchange_world_size_one_cpu():
     assert torch.equal(ex.gathered[slot][0], x)
     with pytest.raises(ValueError):
         ex.gather_async(torch.zeros((2, 4), dtype=torch.int64))
+
+
+def test_ipc_block_offsets_tile_the_receive_buffer():
+    """kind="ipc": rank s writes its [steps][words] block of slot k at ((k * world + s) * steps * words) * 8 bytes of every
+    rank's [slots][world][steps][words] buffer: the blocks of all (slot, sender) pairs tile it without overlap"""
+    from aquaticgymenv_amd.sharded import ipc_block_offset
+    world, steps, words, slots = 3, 5, 4, 2
+    size = steps * words * 8
+    offs = sorted(ipc_block_offset(k, s, world, steps, words) for k in range(slots) for s in range(world))
+    assert offs == [i * size for i in range(slots * world)]
+    import pytest
+    with pytest.raises(ValueError):
+        ipc_block_offset(0, 3, world, steps, words)
+
+
+def test_ipc_kind_has_no_cpu_path():
+    import pytest
+    from aquaticgymenv_amd.sharded import DoneMaskExchange
+    with pytest.raises(RuntimeError):
+        DoneMaskExchange(4, 2, "cpu", kind="ipc")
+    with pytest.raises(ValueError):
+        DoneMaskExchange(4, 2, "cpu", kind="smoke signals")
