@@ -464,6 +464,55 @@ class BatchedAqua(object):
         g.done_history = done if dstride else None
         return g
 
+    # ------------------------------------------------------------------ checkpoint (checkpoint / resume)
+    def state_dict(self):
+        """Everything a later load_state_dict() needs to continue this batch bit for bit: the worlds' state and time markers
+        (incl. the next-step restart bookkeeping), the last step's outputs, the step / reset counters that key the Philox
+        draws, seed, env_offset, restart mode and the obstacle table(s).  Host (CPU) tensors and plain Python values."""
+        torch = self.torch
+        torch.cuda.synchronize(self.device)
+        d = {
+            "format": 1, "num_envs": self.num_envs, "env_offset": self.env_offset, "seed": self.seed,
+            "continuous": self.continuous, "auto_reset": int(self.auto_reset), "waves": self.has_waves,
+            "random_boat": int(self.params.random_boat), "random_goal": int(self.params.random_goal),
+            "tick": self._tick, "resets": self._resets, "per_world": self.per_world,
+            "obstacle_rows": np.array(self.obstacle_rows, dtype=np.float64, copy=True),
+            "state": self.state.cpu().clone(), "time": self.time.cpu().clone(), "reward": self.reward.cpu().clone(),
+            "term": self.term.cpu().clone(), "done_bits": self.done_bits.cpu().clone(),
+        }
+        if self.per_world:
+            d["obstacle_tables"] = np.array(self.obstacle_tables, copy=True)
+        if self.obs_norm_buf is not None:
+            d["obs_norm"] = self.obs_norm_buf.cpu().clone()
+        return d
+
+    def load_state_dict(self, d):
+        """Continue where state_dict() stopped.  The batch must have been constructed with the same shape, seed, offsets,
+        restart mode and obstacles (checked): a checkpoint restores a run, it does not reconfigure one."""
+        same = [("num_envs", self.num_envs), ("env_offset", self.env_offset), ("seed", self.seed), ("continuous", self.continuous),
+                ("auto_reset", int(self.auto_reset)), ("waves", self.has_waves), ("per_world", self.per_world),
+                ("random_boat", int(self.params.random_boat)), ("random_goal", int(self.params.random_goal))]
+        if d.get("format") != 1:
+            raise ValueError("unknown checkpoint format %r" % (d.get("format"),))
+        for key, mine in same:
+            if d[key] != mine:
+                raise ValueError("checkpoint has %s=%r, this batch %r" % (key, d[key], mine))
+        tables = d["obstacle_tables"] if self.per_world else d["obstacle_rows"]
+        mine = self.obstacle_tables if self.per_world else self.obstacle_rows
+        if np.shape(tables) != np.shape(mine) or not np.array_equal(np.asarray(tables), np.asarray(mine)):
+            raise ValueError("checkpoint was taken with other obstacles")
+        for name, dst in (("state", self.state), ("time", self.time), ("reward", self.reward), ("term", self.term),
+                          ("done_bits", self.done_bits)):
+            src = d[name]
+            if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
+                raise ValueError("checkpoint tensor %s is %s %s, expected %s %s" % (name, tuple(src.shape), src.dtype, tuple(dst.shape), dst.dtype))
+            dst.copy_(src)
+        if self.obs_norm_buf is not None and "obs_norm" in d:
+            self.obs_norm_buf.copy_(d["obs_norm"])
+        self._tick, self._resets = int(d["tick"]), int(d["resets"])
+        self._device_tick = -1            # graphs captured on this batch read the tick base from the device: refresh it
+        return self
+
     # ------------------------------------------------------------------ helpers
     def done_mask(self):
         """uint8 [N] done flags unpacked from the ballot words (for checks; step() already returns term)."""

@@ -76,6 +76,11 @@ def parse(argv=None):
     ap.add_argument("--graph-node-events", action="store_true",
                     help="diagnostic: a region that is one graph ALSO carries event-record nodes at its head and tail "
                          "(round 2's clock), reported beside the stream events as roofline.launch_us_graph_nodes_regions")
+    ap.add_argument("--settle-us", type=float, default=0.0,
+                    help="diagnostic: host pause between the barrier that closes a region and the start of the next region's "
+                         "clock (outside every timed interval).  A 20-step graph launched 200 us after a device "
+                         "synchronisation runs 0.15-0.3 us per step faster than one launched right behind it, at the price of "
+                         "3 %% of wall clock (profiles/r03/k20_settle.txt): off by default")
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel (separate line)")
     ap.add_argument("--per-world-tables", action="store_true",
                     help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
@@ -493,6 +498,8 @@ def main(argv=None):
         # `roofline` clock).  Round 2 timed a one-graph region with event-record NODES inside the graph instead: measured
         # side by side (profiles/r03/k20_event_methods.txt) the two nodes add ~7 us of their own to a 100-us graph
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if args.settle_us > 0:
+            time.sleep(args.settle_us * 1e-6)
         t0 = time.perf_counter()
         segs = runner.run(args.steps, before_first_launch=lambda: e0.record(launch_stream),
                           after_last_launch=lambda: e1.record(launch_stream))

@@ -16,17 +16,28 @@ for _cls in ("AquaEnv", "AquaContinuousEnv"):
 difficult_obstacles = _VERSIONS["v2"]["obstacles"]
 
 
+def _registered_ids(module):
+    """ids the gym-like module's registry holds: gym <= 0.21 keeps `registry.env_specs` (a dict), later versions make
+    `registry` itself the dict.  None when no registry can be read."""
+    reg = getattr(module.envs.registration, "registry", None)
+    specs = getattr(reg, "env_specs", reg)
+    try:
+        return set(specs.keys())
+    except Exception:
+        return None
+
+
 def _register_with(module):
     """register the six ids with a gym-like module (anything with envs.registration.register(id=, entry_point=, kwargs=)),
-    as the reference's gym_aqua/__init__.py:4-41 does.  An id that is registered already (the package imported twice)
-    keeps its first registration; any other failure is the caller's to see."""
+    as the reference's gym_aqua/__init__.py:4-41 does.  An id the module's registry already holds (the package imported
+    twice) keeps its first registration -- decided by looking the id up, not by reading an exception's text; every
+    failure of register() itself is the caller's to see."""
     register = module.envs.registration.register
+    have = _registered_ids(module)
     for env_id, (entry, kwargs) in REGISTRY.items():
-        try:
-            register(id=env_id, entry_point=entry, kwargs=kwargs)
-        except Exception as exc:
-            if "register" not in str(exc).lower():      # gym.error.Error("Cannot re-register id: ...")
-                raise
+        if have is not None and env_id in have:
+            continue
+        register(id=env_id, entry_point=entry, kwargs=kwargs)
 
 
 # Classic `gym` only: the classes implement the reference's API (gym 0.17: reset() -> obs, step() -> 4-tuple, no

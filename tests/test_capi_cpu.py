@@ -240,9 +240,12 @@ def test_registration_with_a_gym_like_module(monkeypatch):
     import types
     calls = []
 
+    registry = {}                        # what gym >= 0.22 keeps: id -> spec (older: registry.env_specs)
+
     def register(id=None, entry_point=None, kwargs=None, **extra):
-        if any(c[0] == id for c in calls):
-            raise RuntimeError("Cannot re-register id: %s" % id)
+        if id in registry:
+            raise RuntimeError("id %s is taken" % id)          # (no wording gym_aqua could recognise)
+        registry[id] = (entry_point, kwargs)
         calls.append((id, entry_point, kwargs))
 
     gym = types.ModuleType("gym")
@@ -250,6 +253,7 @@ def test_registration_with_a_gym_like_module(monkeypatch):
     gym.envs = types.ModuleType("gym.envs")
     gym.envs.registration = types.ModuleType("gym.envs.registration")
     gym.envs.registration.register = register
+    gym.envs.registration.registry = registry
     for name, mod in (("gym", gym), ("gym.envs", gym.envs), ("gym.envs.registration", gym.envs.registration)):
         monkeypatch.setitem(sys.modules, name, mod)
 
@@ -272,8 +276,17 @@ def test_registration_with_a_gym_like_module(monkeypatch):
             assert tuple(got[0]) == centre and got[1] == kind and np.all(np.asarray(got[2]) == np.asarray(size))
         assert by_id["AquaContinuousEnv-v2"][2]["obstacles"] is v2
         n = len(calls)
-        importlib.reload(gym_aqua)                       # re-import: "Cannot re-register" is swallowed, nothing is added
+        importlib.reload(gym_aqua)                       # re-import: the ids are found in the registry, nothing is added
         assert len(calls) == n
+        old_style = types.SimpleNamespace(env_specs=dict(registry))    # gym <= 0.21: registry.env_specs
+        gym.envs.registration.registry = old_style
+        importlib.reload(gym_aqua)
+        assert len(calls) == n
+        del registry["AquaEnv-v1"], old_style.env_specs["AquaEnv-v1"]   # one id missing: exactly that one is registered
+        importlib.reload(gym_aqua)
+        assert len(calls) == n + 1 and calls[-1][0] == "AquaEnv-v1"
+        registry.clear()
+        gym.envs.registration.registry = registry
 
         def broken(**kw):
             raise ValueError("something else went wrong")

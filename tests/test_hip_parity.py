@@ -1259,3 +1259,43 @@ def test_rollout_loop_shape_of_the_reference(torch):
                 break
         wins += int(info["Termination.success"])
     assert wins >= 4
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint / resume
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["next_step", "same_step", False])
+def test_checkpoint_resumes_bit_for_bit(torch, mode):
+    """state_dict() after 30 steps, 50 more steps -- against a FRESH batch that loads the checkpoint and runs the same 50
+    steps (eagerly, and as a captured graph): rewards, codes, state, time markers and ballot words equal bit for bit"""
+    from aquaticgymenv_amd import presets
+    n = 5000
+    env = _make(torch, n, presets.BENCH8, seed=11, auto_reset=mode)
+    env.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    acts = torch.randint(0, 3, (80, env.ld), device="cuda:0", generator=g, dtype=torch.int64).to(torch.uint8)
+    env.rollout(30, actions=acts[:30], keep_all=False)
+    ckpt = env.state_dict()
+    assert ckpt["tick"] == 30 and ckpt["state"].device.type == "cpu"
+    rew1, term1 = env.rollout(50, actions=acts[30:], keep_all=True)
+    want = (rew1[:, :n].clone(), term1[:, :n].clone(), env.state[:, :n].clone(), env.time[:n].clone(), env.done_bits.clone())
+    for graph in (False, True):
+        other = _make(torch, n, presets.BENCH8, seed=11, auto_reset=mode)
+        other.reset()
+        other.rollout(3, actions=acts[:3], keep_all=False)             # some other history first
+        other.load_state_dict(ckpt)
+        if graph:
+            gr = other.capture_rollout(50, actions=acts[30:], keep_all=True)
+            rew2, term2 = gr.launch()
+        else:
+            rew2, term2 = other.rollout(50, actions=acts[30:], keep_all=True)
+        torch.cuda.synchronize()
+        got = (rew2[:, :n], term2[:, :n], other.state[:, :n], other.time[:n], other.done_bits)   # (columns past n: padding)
+        for name, a, b in zip(("reward", "term", "state", "time", "done_bits"), want, got):
+            assert torch.equal(a, b), "%s differs after the checkpoint was restored (graph=%s)" % (name, graph)
+        assert other._tick == 80
+    stranger = _make(torch, n, presets.BENCH8, seed=12, auto_reset=mode)
+    with pytest.raises(ValueError):
+        stranger.load_state_dict(ckpt)
+    with pytest.raises(ValueError):
+        _make(torch, n, presets.NONE, seed=11, auto_reset=mode).load_state_dict(ckpt)
