@@ -345,8 +345,8 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
-        if fused and self.per_world and self.K > 8:
-            raise NotImplementedError("the fused per-world rollout keeps tables of at most 8 rows in LDS: longer ones run as "
+        if fused and self.per_world and self.K > 16:
+            raise NotImplementedError("the fused per-world rollout keeps tables of at most 16 rows in LDS: longer ones run as "
                                       "one launch per step (rollout(fused=False) / capture_rollout())")
         with torch.cuda.device(self.device):
             if self.per_world and fused:
@@ -395,8 +395,8 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
-        if fused and self.per_world and self.K > 8:
-            raise NotImplementedError("the fused per-world rollout keeps tables of at most 8 rows in LDS: longer ones are "
+        if fused and self.per_world and self.K > 16:
+            raise NotImplementedError("the fused per-world rollout keeps tables of at most 16 rows in LDS: longer ones are "
                                       "captured as one launch per step (fused=False)")
         self._sync_device_tick()
         cap = torch.cuda.Stream(device=self.device)

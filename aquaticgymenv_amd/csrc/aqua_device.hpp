@@ -780,9 +780,10 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // ROWS == RESEED_HANDOFF8: per-world tables of at most eight rows whose rows the world's OWN lane already holds in
 // registers: it has left them in LDS (`rows` is the group's slot, a per-lane LDS pointer; rows past the table's end
 // repeat its last row) -- no memory round trip at all.  The rare serial scan falls back to the table in memory (`wt`).
-// ROWS == RESEED_SOA8: the same, for a block that keeps the tables of ALL its worlds in LDS as [row][field][lane]
-// (the fused per-world rollout): `rows` points at the world's column, fields RESEED_SOA_STRIDE floats apart.
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA8 = -5;
+// ROWS == RESEED_SOA8 / RESEED_SOA16: the same, for a block that keeps the tables of ALL its worlds in LDS as
+// [row][field][lane] (the fused per-world rollout, tables of up to 8 / 16 rows): `rows` points at the world's column,
+// fields RESEED_SOA_STRIDE floats apart.
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA8 = -5, RESEED_SOA16 = -6;
 constexpr int RESEED_SOA_STRIDE = 256;
 template <int G, int ROWS = 0>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
@@ -847,10 +848,10 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
             }
-        } else if constexpr (ROWS == RESEED_SOA8) {
+        } else if constexpr (ROWS == RESEED_SOA8 || ROWS == RESEED_SOA16) {
             const float* const soa = reinterpret_cast<const float*>(rows);
 #pragma unroll
-            for (int h = 0; h < 8; h += 2) {
+            for (int h = 0; h < (ROWS == RESEED_SOA16 ? 16 : 8); h += 2) {
                 int first_row = h;
                 asm volatile("" : "+v"(first_row));      // (as above: the reads stay next to their use)
                 const float* r = soa + first_row * 5 * RESEED_SOA_STRIDE;
@@ -926,7 +927,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_SOA8) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_SOA8 || ROWS == RESEED_SOA16) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

@@ -493,15 +493,26 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
     uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
+#ifdef AQUA_SS_SYNTH
+    const bool valid0 = static_cast<int64_t>(off) < rem;
+#endif
     constexpr uint32_t own_reset_mask = 0;
     if (RESTART && a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
+#ifdef AQUA_SS_SYNTH
+        // TIMING EXPERIMENT: a synthetic restart set of the usual density that does not depend on the state (the worlds
+        // that really finish keep stepping), so that builds which drop a piece of the restart keep their dynamics
+        const uint32_t synth = (valid0 && ((static_cast<uint32_t>(tile) + off) * 2654435761u + static_cast<uint32_t>(tick) * 40503u) % 54u == 0u) ? 1u : 0u;
+        if (synth) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off);
+        skip_mask = synth;
+#else
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (done_mask & (1u << j)) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off + j);
         }
         skip_mask = done_mask;
+#endif
         AQUA_STAMP(4);      // outputs stored, list appended
         __syncthreads();
         AQUA_STAMP(5);      // barrier passed
@@ -514,12 +525,20 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const uint32_t i = list[active ? q : 0];
             const uint64_t world = static_cast<uint64_t>(a.env_offset + tile) + i;
             EnvState e;
+#ifdef AQUA_SS_NOARITH
+            e.x = 50.0f + static_cast<float>(world & 15u); e.y = 50.0f; e.th = 0.0f; e.gx = 20.0f; e.gy = 80.0f; e.wx = 0.0f; e.wy = 0.0f; e.t = 0;
+#else
             if constexpr (QUICK == QUICK_ALWAYS)
                 e = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
                                                             k.K, k.obst, nullptr, k.quick, k.Kc);
             else
                 e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+#endif
+#ifdef AQUA_SS_NOSTORE
+            if (active && (lane & (RESET_GROUP - 1)) == 0 && e.x == 12345.0f) {
+#else
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
+#endif
                 st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
                 st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
                 st1(row0 + 5 * ld + i, e.wx); st1(row0 + 6 * ld + i, e.wy);
@@ -1401,20 +1420,24 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
 }
 
 // ------------------------------------------------------------------ per-world tables: T steps in one launch
-// rollout_kernel for batches in which every world has its own table (of at most eight rows): the state stays in
-// registers for the whole rollout and the block's tables stay in LDS -- 40 floats per world as [row][field][lane], read
-// conflict-free by the world's own lane in every step and, as a broadcast, by the eight lanes that re-seed it.  Here the
-// LDS tile pays (it did not for the one-launch-per-step kernel): every row is used T times.  HBM traffic per
-// world-step: the action in, reward and term out.  Restart protocol, markers and results: rollout_kernel's, i.e. T launches
-// of the per-step kernels bit for bit.
+// rollout_kernel for batches in which every world has its own table (of at most KT = 8 or 16 rows): the state stays in
+// registers for the whole rollout and the block's tables stay in LDS -- 5 KT floats per world as [row][field][lane] (40 or
+// 80 KB per 256-world block), read conflict-free by the world's own lane in every step and, as a broadcast, by the eight
+// lanes that re-seed it.  Here the LDS tile pays (it did not for the one-launch-per-step kernel): every
+// row is used T times.  HBM traffic per world-step: the action in, reward and term out.  Restart protocol, markers and
+// results: rollout_kernel's, i.e. T launches of the per-step kernels bit for bit.  (Longer tables do not fit the LDS of a
+// CU beside a second block; they run as one launch per step.)
 static_assert(RESEED_SOA_STRIDE == BLOCK_SMALL, "one column of the LDS table tile per lane");
+constexpr int FUSED_TABLE_ROWS_MAX = 16;
+template <int KT>
 struct RolloutTablesShared {
     RolloutShared r;
-    float rows[8 * 5][BLOCK_SMALL];
+    float rows[KT * 5][BLOCK_SMALL];
 };
 
+template <int KT>
 __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, const StepArgs& a, uint64_t tick, int64_t block_first_world,
-                                                    RolloutTablesShared& sh, int parity, const float* __restrict__ t32_tile, int64_t tld)
+                                                    RolloutTablesShared<KT>& sh, int parity, const float* __restrict__ t32_tile, int64_t tld)
 {
     constexpr int WAVES = BLOCK_SMALL / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1433,7 +1456,7 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
         const uint32_t owner = sh.r.list[parity][seg][active ? q - first[seg] : 0];
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
         const WorldTable own{t32_tile, nullptr, tld, owner};
-        const EnvState f = reset_env_group<RESET_GROUP, RESEED_SOA8>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
+        const EnvState f = reset_env_group<RESET_GROUP, KT == 16 ? RESEED_SOA16 : RESEED_SOA8>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
                                                                       nullptr, reinterpret_cast<const ObstF*>(&sh.rows[0][owner]), nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.r.result[q];
@@ -1442,11 +1465,11 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
     }
 }
 
-template <int AK, int MODE>
-__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 3))) void rollout_tables_kernel(
-    const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
+template <int AK, int MODE, int KT>
+__device__ __forceinline__ void rollout_tables_body(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
+                                                    int64_t tld, float band2, float band2_tight, RolloutTablesShared<KT>& sh)
 {
-    __shared__ RolloutTablesShared sh;
+    static_assert(KT == 8 || KT == 16, "LDS tile of 8 or 16 rows");
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K; k.Kc = 0;
     k.band2 = band2; k.band2_tight = band2_tight; k.obst = nullptr; k.obst64 = nullptr; k.quick = nullptr;
@@ -1463,8 +1486,8 @@ __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 
                    a.state[4 * ld + ic], a.state[5 * ld + ic], a.state[6 * ld + ic], a.time[ic]};
         __syncthreads();                                   // (a block that iterates: the last tile's columns are no longer read)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int jj = j < a.K ? j : a.K - 1;          // uniform; 1 <= a.K <= 8
+        for (int j = 0; j < KT; ++j) {
+            const int jj = j < a.K ? j : a.K - 1;          // uniform; 1 <= a.K <= KT
             const float* const rb = t32 + (6 * jj) * tld + bbase;
 #pragma unroll
             for (int f = 0; f < 5; ++f) sh.rows[j * 5 + f][threadIdx.x] = rb[f * tld + off];
@@ -1507,14 +1530,14 @@ __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 
             EnvState after = e;
             float rew;
             uint32_t code;
-            ObstF rows[8];                                  // this step's copy of the lane's column
+            ObstF rows[KT];                                 // this step's copy of the lane's column
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < KT; ++j) {
                 rows[j].cx = sh.rows[j * 5 + 0][threadIdx.x]; rows[j].cy = sh.rows[j * 5 + 1][threadIdx.x];
                 rows[j].hx = sh.rows[j * 5 + 2][threadIdx.x]; rows[j].hy = sh.rows[j * 5 + 3][threadIdx.x];
                 rows[j].r2 = sh.rows[j * 5 + 4][threadIdx.x]; rows[j].w = 1.0f;
             }
-            const bool knife = fast_step<true, QUICK_NEVER, 8>(after, m.h, m.w, m.chord, u0, u1, k, rew, code, &wt, rows) && valid && !pending;
+            const bool knife = fast_step<true, QUICK_NEVER, KT>(after, m.h, m.w, m.chord, u0, u1, k, rew, code, &wt, rows) && valid && !pending;
             if (any_lane(knife)) {
                 if (knife) {
                     const ExactOut o = exact_step_world(before.x, before.y, before.th, before.gx, before.gy, before.wx, before.wy,
@@ -1546,6 +1569,23 @@ __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 
             a.time[i] = e.t;
         }
     }
+}
+
+template <int AK, int MODE>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 3))) void rollout_tables_kernel(
+    const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
+{
+    __shared__ RolloutTablesShared<8> sh;
+    rollout_tables_body<AK, MODE, 8>(a, t32, t64, tld, band2, band2_tight, sh);
+}
+
+// tables of 9..16 rows: 80 KB of LDS per block, two blocks per CU
+template <int AK, int MODE>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(1, 2))) void rollout_tables16_kernel(
+    const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
+{
+    __shared__ RolloutTablesShared<16> sh;
+    rollout_tables_body<AK, MODE, 16>(a, t32, t64, tld, band2, band2_tight, sh);
 }
 
 // Masked reset against per-world tables.  A block reads the mask of RESET_SCAN worlds and compacts the selected ones
@@ -2269,8 +2309,9 @@ int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, c
 {
     StepArgs a;
     if (auto_reset < 0 || auto_reset > 2) return fail(AQUA_E_INVALID, "auto_reset must be 0, 1 or 2");
-    if (K > TABLES_KREG)
-        return fail(AQUA_E_INVALID, "the fused per-world rollout keeps tables of at most %d rows in LDS (K=%d): use aqua_rollout_tables_f32", TABLES_KREG, K);
+    if (K > FUSED_TABLE_ROWS_MAX)
+        return fail(AQUA_E_INVALID, "the fused per-world rollout keeps tables of at most %d rows in LDS (K=%d): use aqua_rollout_tables_f32", FUSED_TABLE_ROWS_MAX, K);
+    const bool wide = K > TABLES_KREG;                   // 9..16 rows: the 80 KB tile
     int rc = fill_table_args(a, p, tab32_dev, K, tld, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
     if (rc) return rc;
     TableArgs t;
@@ -2284,13 +2325,16 @@ int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, c
     a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;
     const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
+#define AQUA_ROLLOUT_TABLES_MODE(KERNEL, AK)                                                                                 \
+        if (auto_reset == AQUA_RESET_NEXT_STEP)                                                                              \
+            hipLaunchKernelGGL((KERNEL<AK, AQUA_RESET_NEXT_STEP>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else if (auto_reset == AQUA_RESET_SAME_STEP)                                                                         \
+            hipLaunchKernelGGL((KERNEL<AK, AQUA_RESET_SAME_STEP>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        else hipLaunchKernelGGL((KERNEL<AK, 0>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight);
 #define AQUA_ROLLOUT_TABLES(AK)                                                                                              \
     case AK:                                                                                                                 \
-        if (auto_reset == AQUA_RESET_NEXT_STEP)                                                                              \
-            hipLaunchKernelGGL((rollout_tables_kernel<AK, AQUA_RESET_NEXT_STEP>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else if (auto_reset == AQUA_RESET_SAME_STEP)                                                                         \
-            hipLaunchKernelGGL((rollout_tables_kernel<AK, AQUA_RESET_SAME_STEP>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
-        else hipLaunchKernelGGL((rollout_tables_kernel<AK, 0>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight); \
+        if (wide) { AQUA_ROLLOUT_TABLES_MODE(rollout_tables16_kernel, AK) }                                                  \
+        else { AQUA_ROLLOUT_TABLES_MODE(rollout_tables_kernel, AK) }                                                         \
         break;
     switch (action_kind) {
         AQUA_ROLLOUT_TABLES(AQUA_ACT_U8)
@@ -2301,6 +2345,7 @@ int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, c
         AQUA_ROLLOUT_TABLES(AQUA_ACT_SAMPLE_C)
         AQUA_ROLLOUT_TABLES(AQUA_ACT_BEARING)
 #undef AQUA_ROLLOUT_TABLES
+#undef AQUA_ROLLOUT_TABLES_MODE
         default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
     }
     const hipError_t e = hipGetLastError();

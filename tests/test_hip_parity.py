@@ -633,10 +633,73 @@ def test_per_world_tables_rollout_and_graph_equal_single_steps(torch, mode):
         assert torch.equal(fused.state, ref.state) and torch.equal(fused.time, ref.time)
         if actions != "stored":
             assert torch.equal(fgraph.state, ref.state) and torch.equal(fgraph.time, ref.time)
-    long_tables = _make(torch, 100, _random_tables(rng, 100, 11), seed=1, auto_reset=mode)
+    long_tables = _make(torch, 100, _random_tables(rng, 100, 17), seed=1, auto_reset=mode)
     long_tables.reset()
     with pytest.raises(NotImplementedError):
-        long_tables.rollout(T, fused=True)                 # more than 8 rows do not fit the LDS tile
+        long_tables.rollout(T, fused=True)                 # more than 16 rows do not fit the LDS tile
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["none", "same_step", "next_step"])
+@pytest.mark.parametrize("K", [11, 16])
+def test_long_per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mode):
+    """per-world tables of more than eight rows (aqua.py:56-68: a list of any length per env object): the one-launch-per-step
+    kernels against the oracle's step_tables / reset_tables in every restart mode (codes and markers bit-exact, restarted
+    worlds bit for bit, floats within 1e-5), and the fused rollout -- its 16-row LDS tile -- against those launches, bit
+    for bit, eagerly and as a replayed graph"""
+    n, T = 9000 + 5, 24
+    rng = np.random.RandomState(100 + K)
+    tables = _random_tables(rng, n, K)
+    acts = torch.as_tensor(rng.randint(0, 3, (T, n)).astype(np.uint8)).cuda()
+    env = _make(torch, n, tables, seed=77, auto_reset=mode, env_offset=64)
+    env.reset()
+    want_r, want_t, restarted = [], [], 0
+    for it in range(T):
+        st, tt = _host_state(env)
+        st, tt = st.copy(), tt.copy()
+        tick = env._tick
+        _, reward, term = env.step(acts[it])
+        torch.cuda.synchronize()
+        want_r.append(reward.clone()); want_t.append(term.clone())
+        act = acts[it].cpu().numpy()
+        k_state, k_time = _host_state(env)
+        if mode == 2:
+            was_restart = tt == -1 - ((tick - 1) & 1)
+            o_rew, o_term = _oracle_next_step_tables(oracle, st, tt, act, tables, 77, tick, 64)
+            assert np.array_equal(k_time, tt)
+            assert np.array_equal(k_state[:, was_restart], st[:, was_restart])
+            moved = ~was_restart
+            restarted += int(was_restart.sum())
+        else:
+            s64 = np.ascontiguousarray(st.astype(np.float64))
+            o_rew, o_term, _ = oracle.step_tables(s64, tt, act, tables, waves=1, seed=77, tick=tick, env_offset=64)
+            moved = np.ones(n, dtype=bool)
+            st = s64.astype(np.float32)
+            if mode == 1:                                   # same-step restart == masked reset with the step's tick
+                fin = o_term != 0
+                fresh = np.ascontiguousarray(st.copy())
+                oracle.reset_tables(fresh, tt, tables, waves=1, seed=77, tick=tick, env_offset=64, mask=fin)
+                assert np.array_equal(k_state[:, fin], fresh[:, fin]) and np.all(k_time[fin] == 0)
+                moved = ~fin
+                restarted += int(fin.sum())
+            o_rew = o_rew.astype(np.float32)
+        assert np.array_equal(term.cpu().numpy(), o_term)
+        assert np.max(np.abs(reward.cpu().numpy() - o_rew)) <= TOL
+        assert np.max(np.abs(k_state[0:2, moved] - st[0:2, moved])) <= TOL
+        assert np.max(angle_diff(k_state[2, moved], st[2, moved])) <= TOL
+        assert np.max(np.abs(k_state[5:7, moved] - st[5:7, moved])) <= 1e-7
+    if mode:
+        assert restarted > n // 20
+    fused, fgraph = (_make(torch, n, tables, seed=77, auto_reset=mode, env_offset=64) for _ in range(2))
+    fused.reset(); fgraph.reset()
+    r, c = fused.rollout(T, actions=acts, fused=True, keep_all=True)
+    g = fgraph.capture_rollout(T, actions=acts, fused=True, keep_all=True)
+    r2, c2 = g.launch()
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(r[t, :n], want_r[t]) and torch.equal(c[t, :n], want_t[t]), "fused rollout differs at step %d" % t
+        assert torch.equal(r2[t, :n], want_r[t]) and torch.equal(c2[t, :n], want_t[t])
+    for other in (fused, fgraph):
+        assert torch.equal(other.state[:, :n], env.state[:, :n]) and torch.equal(other.time[:n], env.time[:n])
 
 
 def test_per_world_next_step_equals_the_shared_table_kernel(torch):
