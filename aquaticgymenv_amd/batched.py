@@ -73,7 +73,7 @@ class BatchedAqua(object):
     """
 
     def __init__(self, num_envs, obstacles=False, waves=True, random_boat=True, random_goal=True, continuous=False,
-                 device=None, seed=None, env_offset=0, auto_reset=True, normalized_obs=False):
+                 device=None, seed=None, env_offset=0, auto_reset=True, normalized_obs=False, count_clipped=False):
         import torch
         self.torch = torch
         if num_envs < 1:
@@ -138,6 +138,10 @@ class BatchedAqua(object):
             self._tick_dev = torch.zeros(2, dtype=torch.int64, device=dev)      # [0] tick base of captured graphs, [1] scratch
             # optional fused epilogue (main/impl/utils.py:15-33): obs / (high - low), angle + 0.5
             self.obs_norm_buf = torch.zeros((5, self.ld), dtype=torch.float32, device=dev) if normalized_obs else None
+        # aqua.py:145-150 prints a message when a continuous action is outside [0.2, 0.5] and clips it.  The kernels clip
+        # silently; with count_clipped=True every step()/rollout() with a caller-provided action buffer also adds the number of
+        # WORLDS whose action was clipped to this device counter (two small torch reductions, no sync)
+        self.clipped_actions = (torch.zeros((), dtype=torch.int64, device=dev) if (count_clipped and self.continuous) else None)
         self._tick = 0                    # one per step: draws of the step, and of the restarts the step kernels do
         self._device_tick = 0
         self._resets = 0                  # one per reset() call: its draws use tick RESET_TICK_BASE + _resets, so
@@ -188,6 +192,7 @@ class BatchedAqua(object):
             if soa:
                 if a.dim() != 2 or a.shape[0] != 2 or a.shape[1] < n or a.stride(1) != 1:
                     raise ValueError("soa action must be a float32 [2][>=N] tensor with unit inner stride")
+                self._count_clipped(a[:, :n])
                 return a, a.data_ptr(), _capi.ACT_F32X2, a.stride(0)
             if a.dim() == 1 and n == 1:
                 a = a.reshape(1, 2)
@@ -196,6 +201,7 @@ class BatchedAqua(object):
             if self._action_soa is None:
                 self._action_soa = torch.empty((2, self.ld), dtype=torch.float32, device=self.device)
             self._action_soa[:, :n].copy_(a.t())
+            self._count_clipped(self._action_soa[:, :n])
             return self._action_soa, self._action_soa.data_ptr(), _capi.ACT_F32X2, self.ld
         a = action
         if not isinstance(a, torch.Tensor):
@@ -217,6 +223,12 @@ class BatchedAqua(object):
                 raise ValueError("expected %d actions, got %d" % (n, a.numel()))
             a = a.contiguous()
         return a, a.data_ptr(), kind, 0
+
+    def _count_clipped(self, thrusts):
+        """thrusts float32 [..., 2, n]: adds the worlds with a thrust outside [0.2, 0.5] (aqua.py:145-150) to the counter"""
+        if self.clipped_actions is not None:
+            out = (thrusts < 0.2) | (thrusts > 0.5)
+            self.clipped_actions += out.any(dim=-2).sum()
 
     # ------------------------------------------------------------------ the path
     RESET_TICK_BASE = 1 << 40             # reset() draws live far above any step tick
@@ -305,6 +317,7 @@ class BatchedAqua(object):
             if actions.dtype != torch.float32 or actions.dim() != 3 or actions.shape[0] < steps or actions.shape[1] != 2 \
                     or actions.shape[2] < n or actions.stride(2) != 1:
                 raise ValueError("continuous rollout actions must be float32 [T][2][>=N]")
+            self._count_clipped(actions[:steps, :, :n])
             return actions.data_ptr(), _capi.ACT_F32X2, actions.stride(1), actions.stride(0)
         kinds = {torch.uint8: _capi.ACT_U8, torch.int32: _capi.ACT_I32, torch.int64: _capi.ACT_I64}
         if actions.dtype not in kinds or actions.dim() != 2 or actions.shape[0] < steps or actions.shape[1] < n \

@@ -422,6 +422,13 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baselines(args, obstacles)          # before anything touches the GPU (see the docstring)
 
+    # rank 0's ONE JSON line is the only thing this process may put on stdout: RCCL prints a version banner there when its
+    # communicator comes up, other libraries may chat too.  From here on file descriptor 1 is stderr; the line goes to
+    # a private duplicate of the original stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -574,7 +581,10 @@ def main(argv=None):
             result["extras"] = extras(env, torch, n, a_bytes)
         if args.per_world_tables and world == 1:
             result.setdefault("extras", {})["per_world_tables"] = per_world_tables(torch, np, presets, BatchedAqua, n, dev)
-        print(json.dumps(result), flush=True)
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
+    if exchange is not None:
+        exchange.stop()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

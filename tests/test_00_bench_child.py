@@ -25,8 +25,9 @@ def _run(cmd, timeout=900):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, "rc %d\n--- stdout\n%s\n--- stderr\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line expected, got %d:\n%s" % (len(lines), p.stdout[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), \
+        "stdout must hold exactly one line, the JSON line (RCCL's banner and everything else belong on stderr):\n%s" % p.stdout[-2000:]
     return json.loads(lines[0])
 
 

@@ -1362,3 +1362,25 @@ def test_checkpoint_resumes_bit_for_bit(torch, mode):
         stranger.load_state_dict(ckpt)
     with pytest.raises(ValueError):
         _make(torch, n, presets.NONE, seed=11, auto_reset=mode).load_state_dict(ckpt)
+
+
+def test_clipped_action_counter(torch):
+    """aqua.py:145-150 prints and clips a continuous action outside [0.2, 0.5]; the batched path clips in the kernel and --
+    with count_clipped=True -- counts the worlds it clipped for"""
+    from aquaticgymenv_amd import presets
+    n = 1000
+    env = _make(torch, n, presets.NONE, continuous=True, seed=3, count_clipped=True)
+    env.reset()
+    a = torch.full((n, 2), 0.3, device="cuda:0")
+    a[10, 0] = 0.1; a[20, 1] = 0.9; a[30] = torch.tensor([0.0, 1.0], device="cuda:0")      # three worlds, four thrusts
+    env.step(a)
+    assert int(env.clipped_actions) == 3
+    soa = torch.full((2, env.ld), 0.5, device="cuda:0")
+    soa[0, 5] = 0.5001
+    env.step(soa, soa=True)
+    assert int(env.clipped_actions) == 4
+    acts = torch.full((6, 2, env.ld), 0.2, device="cuda:0")
+    acts[2, 1, 7] = 0.19; acts[4, 0, 7] = 0.6; acts[5, 0, env.ld - 1] = 9.0                 # (the last one is padding: not a world)
+    env.rollout(6, actions=acts)
+    assert int(env.clipped_actions) == 6
+    assert _make(torch, n, presets.NONE, continuous=True).clipped_actions is None
