@@ -98,6 +98,20 @@ class DoneMaskExchange(object):
             self._side = [torch.cuda.Stream(device=self.device)] if self.device.type == "cuda" else []
 
     # ------------------------------------------------------------------ kind="ipc"
+    def _agree(self, error, what):
+        """Every rank reports whether `what` worked for it; if it failed ANYWHERE, every rank raises -- together, so that no
+        rank goes on to a collective the others never reach (a one-sided fallback would hang the job)."""
+        if not self.collective:
+            if error is not None:
+                raise RuntimeError("%s failed: %s: %s" % (what, type(error).__name__, error))
+            return
+        mine = None if error is None else "%s: %s" % (type(error).__name__, error)
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, mine, group=self.group)
+        failed = ["rank %d: %s" % (r, m) for r, m in enumerate(everyone) if m is not None]
+        if failed:
+            raise RuntimeError("%s failed on %d of %d ranks (%s)" % (what, len(failed), self.world, "; ".join(failed)))
+
     def _setup_ipc(self):
         import ctypes
         from . import _capi
@@ -106,31 +120,76 @@ class DoneMaskExchange(object):
             raise RuntimeError("DoneMaskExchange(kind='ipc') moves device buffers between GPU processes: device must be a HIP device")
         lib = _capi.lib
         nbytes = self.slots * self.world * self.steps * self.words * 8
-        with torch.cuda.device(self.device):
-            buf = ctypes.c_void_p()
-            _capi.check(lib.aqua_ipc_buffer_create(nbytes, ctypes.byref(buf)), "aqua_ipc_buffer_create")
-            handle = ctypes.create_string_buffer(_capi.IPC_HANDLE_BYTES)
-            _capi.check(lib.aqua_ipc_buffer_handle(buf, handle), "aqua_ipc_buffer_handle")
-            base = int(lib.aqua_ipc_buffer_ptr(buf))
+        buf, base, raw, err = ctypes.c_void_p(), 0, b"", None
+        try:                                   # (1) the own receive buffer and its handle: local, nothing collective in here
+            with torch.cuda.device(self.device):
+                _capi.check(lib.aqua_ipc_buffer_create(nbytes, ctypes.byref(buf)), "aqua_ipc_buffer_create")
+                handle = ctypes.create_string_buffer(_capi.IPC_HANDLE_BYTES)
+                _capi.check(lib.aqua_ipc_buffer_handle(buf, handle), "aqua_ipc_buffer_handle")
+                base, raw = int(lib.aqua_ipc_buffer_ptr(buf)), bytes(handle.raw)
+        except Exception as exc:
+            err = exc
+        handles = [raw]
+        if self.collective:                    # (2) every rank takes part, whatever happened to it in (1)
             handles = [None] * self.world
-            if self.collective:
-                dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
-            else:
-                handles[0] = bytes(handle.raw)
-            peers = [None] * self.world
-            peers[self.rank] = base
-            for r in range(self.world):
-                if r != self.rank:
-                    p = ctypes.c_void_p()
-                    _capi.check(lib.aqua_ipc_open(handles[r], ctypes.byref(p)), "aqua_ipc_open (rank %d)" % r)
-                    peers[r] = int(p.value)
+            dist.all_gather_object(handles, raw, group=self.group)
+        peers = [None] * self.world
+        if err is None:
+            try:                               # (3) map the others: local again
+                peers[self.rank] = base
+                with torch.cuda.device(self.device):
+                    for r in range(self.world):
+                        if r != self.rank:
+                            if not handles[r]:
+                                raise RuntimeError("rank %d exported no buffer" % r)
+                            p = ctypes.c_void_p()
+                            _capi.check(lib.aqua_ipc_open(handles[r], ctypes.byref(p)), "aqua_ipc_open (rank %d)" % r)
+                            peers[r] = int(p.value)
+            except Exception as exc:
+                err = exc
+        try:
+            self._agree(err, "mapping the done-mask receive buffers (hipIpcMemHandle)")     # (4) all or nobody
+        except Exception:
+            for r, p in enumerate(peers):
+                if r != self.rank and p:
+                    lib.aqua_ipc_close(p)
+            if buf.value:
+                lib.aqua_ipc_buffer_destroy(buf)
+            raise
+        with torch.cuda.device(self.device):
             whole = torch.as_tensor(_DevicePointerArray(base, (self.slots, self.world, self.steps, self.words)), device=self.device)
         self._ipc = {"lib": lib, "buf": buf, "peers": peers, "whole": whole}
         self.gathered = [whole[s] for s in range(self.slots)]
         # one side stream per destination (the own slot included): the copies of one block run side by side
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.world)]
+
+    def probe(self):
+        """kind="ipc": one block with a rank-specific pattern through the whole path (pump, side streams, every peer), then
+        every rank checks every block.  Raises on ALL ranks if it failed on any (bench.py then falls back to RCCL)."""
+        torch = self.torch
+        base = torch.arange(self.steps * self.words, dtype=torch.int64, device=self.device).reshape(self.steps, self.words)
+        err, slot, slot2 = None, 0, 0
+        try:                                   # both publish paths: pump + side streams, then the in-stream fan-out launch
+            slot = self.gather_async(base + (self.rank + 1) * 1000003)
+            slot2 = self.gather_async(base - (self.rank + 1) * 7919, final=True)
+        except Exception as exc:
+            err = exc
+        try:
+            self.finish()
+        except Exception as exc:
+            err = err or exc
         if self.collective:
-            dist.barrier(group=self.group)        # everybody has mapped everybody before the first copy
+            self.dist.barrier(group=self.group)
+        self._since_fence = 0
+        if err is None:
+            try:
+                for r in range(self.world):
+                    if not torch.equal(self.gathered[slot][r], base + (r + 1) * 1000003) \
+                            or not torch.equal(self.gathered[slot2][r], base - (r + 1) * 7919):
+                        raise RuntimeError("the probe blocks of rank %d did not arrive intact" % r)
+            except Exception as exc:
+                err = exc
+        self._agree(err, "the probe exchange through the mapped buffers")
 
     def close(self):
         """unmap the peers' buffers and free the own one (after a fence(): nobody may still be writing into it)"""

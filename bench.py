@@ -386,16 +386,11 @@ def make_exchange(kind, block_rows, words, dev, slots, rank, world, torch, DoneM
     other rank's buffer AND a probe block arrives intact everywhere, else RCCL's all-gather."""
     note = None
     if kind in ("auto", "ipc"):
+        # setup and probe agree across the ranks before they return or raise (sharded.DoneMaskExchange._agree): either every
+        # rank uses the mapped buffers or every rank falls back -- a one-sided fallback would hang the job
         try:
             ex = DoneMaskExchange(block_rows, words, dev, kind="ipc", slots=max(2, slots), copy_engine=copy_engine)
-            probe = (torch.arange(block_rows * words, dtype=torch.int64, device=dev).reshape(block_rows, words)
-                     + (rank + 1) * 1000003)
-            slot = ex.gather_async(probe)
-            ex.fence()
-            for r in range(world):
-                expect = probe - (rank + 1) * 1000003 + (r + 1) * 1000003
-                if not torch.equal(ex.gathered[slot][r], expect):
-                    raise RuntimeError("probe block of rank %d did not arrive intact" % r)
+            ex.probe()
             return ex, "ipc", None
         except Exception as exc:
             if kind == "ipc":

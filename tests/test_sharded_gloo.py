@@ -188,3 +188,31 @@ def test_ipc_kind_has_no_cpu_path():
         DoneMaskExchange(4, 2, "cpu", kind="ipc")
     with pytest.raises(ValueError):
         DoneMaskExchange(4, 2, "cpu", kind="smoke signals")
+
+
+def _agree_worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = DoneMaskExchange(2, 4, "cpu")
+        ex._agree(None, "nothing")                                   # nobody failed: nobody raises
+        outcome = "no error"
+        try:
+            ex._agree(ValueError("cannot map rank 0") if rank == 1 else None, "the mapping")
+        except RuntimeError as exc:
+            outcome = str(exc)
+        with open(os.path.join(tmpdir, "agree%d.txt" % rank), "w") as f:
+            f.write(outcome)
+        dist.barrier()                                               # both are still in step with each other
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_is_raised_on_every_rank(tmp_path):
+    """the IPC exchange decides 'mapped buffers or RCCL' for the whole job: a rank whose mapping (or probe) failed makes
+    EVERY rank raise -- a rank that fell back alone would sit in a collective the others never reach"""
+    mp.spawn(_agree_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        text = (tmp_path / ("agree%d.txt" % rank)).read_text()
+        assert "the mapping failed on 1 of 2 ranks" in text and "rank 1: ValueError: cannot map rank 0" in text
