@@ -90,6 +90,8 @@ class DoneMaskExchange(object):
         self._since_fence = 0
         self._ipc = None
         self._pump = None
+        self._deferred = {}               # slot -> job whose copies have not been handed to the pump yet
+        self._side_used = False           # the pump has queued work on the side streams since the last finish()
         if kind == "ipc":
             self._setup_ipc()
         else:
@@ -158,7 +160,10 @@ class DoneMaskExchange(object):
             raise
         with torch.cuda.device(self.device):
             whole = torch.as_tensor(_DevicePointerArray(base, (self.slots, self.world, self.steps, self.words)), device=self.device)
-        self._ipc = {"lib": lib, "buf": buf, "peers": peers, "whole": whole}
+        import ctypes as _ct
+        fanout = [(_ct.c_void_p * self.world)(*[p + ipc_block_offset(k, self.rank, self.world, self.steps, self.words) for p in peers])
+                  for k in range(self.slots)]       # per slot: where this rank's block goes in every rank's buffer
+        self._ipc = {"lib": lib, "buf": buf, "peers": peers, "whole": whole, "fanout": fanout}
         self.gathered = [whole[s] for s in range(self.slots)]
         # one side stream per destination (the own slot included): the copies of one block run side by side
         self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.world)]
@@ -213,6 +218,9 @@ class DoneMaskExchange(object):
         """host: until the pump has queued the job's copies (the GPU has reached the block's last step); then its events"""
         if job is None:
             return ()
+        for s, j in list(self._deferred.items()):      # somebody needs it now: it cannot stay deferred
+            if j is job:
+                self.publish(s)
         job.submitted.wait()
         if job.error is not None:
             raise job.error
@@ -231,13 +239,15 @@ class DoneMaskExchange(object):
         (call before the kernels that overwrite that buffer)."""
         self._wait_events(self._job_events(self._source_busy.pop(source_id, None)))
 
-    def gather_async(self, local_bits, source_id=None, final=False):
+    def gather_async(self, local_bits, source_id=None, final=False, defer=False):
         """Queue the exchange of local_bits ([steps][words] int64, contiguous).  Returns the slot index whose
         `gathered[slot]` holds the result: after wait(slot) for kind="rccl", after the next fence() for kind="ipc".
         final=True: nothing follows this block on the producing stream before the caller drains it (the last block of a
         timed region).  kind="ipc" then delivers it with ONE fan-out launch on the producing stream itself, in stream
-        order behind the block's last step: no host round trip, no second stream, no thread hand-off -- which is what
-        a 100-microsecond region can afford."""
+        order behind the block's last step: no host round trip, no second stream, no thread hand-off.
+        defer=True: only the block's completion event is recorded now; the copies are queued by publish(slot) -- which a
+        caller that works in short bursts calls at the START of its next burst, so that the block travels while the next
+        steps run (the mask is consumed one block late, as SURVEY.md section 8e plans it) instead of behind an idle GPU."""
         torch, dist = self.torch, self.dist
         if tuple(local_bits.shape) != (self.steps, self.words) or local_bits.dtype != torch.int64 \
                 or not local_bits.is_contiguous():
@@ -262,21 +272,17 @@ class DoneMaskExchange(object):
         # every transport, RCCL included, look equally expensive).  The wait happens on the HOST instead: a pump thread
         # sleeps in hipEventSynchronize and queues the copies once the block is complete.
         if self.kind == "ipc" and final:
+            # one launch on the producing stream.  Everything this rank does with the source buffer or with the slot afterwards
+            # is queued behind that launch (later step launches: same stream; later copies: behind a later event of that
+            # stream), so the job needs no event of its own -- the host path of a 100-microsecond region stays short
             import ctypes
             from . import _capi
             cur = torch.cuda.current_stream(self.device)
-            offset = ipc_block_offset(slot, self.rank, self.world, self.steps, self.words)
-            dsts = (ctypes.c_void_p * self.world)(*[p + offset for p in self._ipc["peers"]])
-            with torch.cuda.device(self.device):
-                _capi.check(self._ipc["lib"].aqua_copy_fanout_async(dsts, self.world, local_bits.data_ptr(),
-                                                                    self.steps * self.words * 8, ctypes.c_void_p(cur.cuda_stream)),
-                            "aqua_copy_fanout_async")
-            job = _ExchangeJob(None)
-            job.events.append(cur.record_event())
-            job.submitted.set()
-            self._pending[slot] = job
-            if source_id is not None:
-                self._source_busy[source_id] = job
+            _capi.check(self._ipc["lib"].aqua_copy_fanout_async(self._ipc["fanout"][slot], self.world, local_bits.data_ptr(),
+                                                                self.steps * self.words * 8, ctypes.c_void_p(cur.cuda_stream)),
+                        "aqua_copy_fanout_async")
+            self._pending[slot] = None
+            self._source_busy.pop(source_id, None)
             return slot
         job = _ExchangeJob(torch.cuda.current_stream(self.device).record_event())
         if self.kind == "ipc":
@@ -306,11 +312,21 @@ class DoneMaskExchange(object):
                 job.events.append(side.record_event())
         job.submit = submit
         job.keep = local_bits                  # the source stays alive until its copies have been queued
-        self._pump_put(job)
         self._pending[slot] = job
         if source_id is not None:
             self._source_busy[source_id] = job
+        if defer:
+            self._deferred[slot] = job
+        else:
+            self._pump_put(job)
         return slot
+
+    def publish(self, slot=None):
+        """hand the deferred block of `slot` (all deferred blocks when None) to the pump"""
+        for s in (list(self._deferred) if slot is None else [slot]):
+            job = self._deferred.pop(s, None)
+            if job is not None:
+                self._pump_put(job)
 
     def _pump_put(self, job):
         import queue
@@ -326,6 +342,7 @@ class DoneMaskExchange(object):
                         return
                     try:
                         j.ready.synchronize()      # host-side wait (hipEventSynchronize; the GIL is released)
+                        self._side_used = True
                         j.submit()
                     except BaseException as exc:   # handed to whoever waits for the job
                         j.error = exc
@@ -342,12 +359,20 @@ class DoneMaskExchange(object):
             self._pending[s] = None
 
     def finish(self):
-        """Host-side completion of everything this rank queued (end of a timed region)."""
-        self.wait()
+        """Host-side completion of everything this rank queued AND handed to the pump (end of a timed region); a block
+        that is still deferred stays deferred."""
+        deferred = set(id(j) for j in self._deferred.values())
+        for s in range(self.slots):
+            if self._pending[s] is not None and id(self._pending[s]) not in deferred:
+                self._wait_events(self._job_events(self._pending[s]))
+                self._pending[s] = None
         for job in list(self._source_busy.values()):
-            self._job_events(job)
-        for st in self._side:
-            st.synchronize()
+            if id(job) not in deferred:
+                self._job_events(job)
+        if self._side_used:
+            self._side_used = False
+            for st in self._side:
+                st.synchronize()
 
     def fence(self):
         """finish() + a barrier over the group: every block published before it, by ANY rank, is in place in gathered[];

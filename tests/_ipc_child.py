@@ -42,6 +42,20 @@ def main():
                 got = ex.gathered[slot][r]
                 assert torch.equal(got, block(r, kk, steps, words, dev)), "rank %d: block %d of rank %d is wrong" % (rank, kk, r)
         dist.barrier()                      # nobody publishes the next round before everybody has checked this one
+    # a deferred block (bench.py: the last block of a region) stays put across a fence and travels with the next burst
+    with torch.cuda.stream(work):
+        held = block(rank, 1000, steps, words, dev)
+        slot_held = ex.gather_async(held, source_id=0, defer=True)
+    ex.fence()
+    with torch.cuda.stream(work):
+        ex.publish(slot_held)
+        nxt = block(rank, 1001, steps, words, dev)
+        slot_next = ex.gather_async(nxt, source_id=1)
+    ex.fence()
+    for r in range(world):
+        assert torch.equal(ex.gathered[slot_held][r], block(r, 1000, steps, words, dev)), "deferred block of rank %d" % r
+        assert torch.equal(ex.gathered[slot_next][r], block(r, 1001, steps, words, dev))
+    dist.barrier()
     # more blocks than slots between two fences must be refused, not silently overwrite a peer's unread block
     try:
         for j in range(slots + 1):
