@@ -127,12 +127,16 @@ class StepRunner(object):
         self.use_graph, self.chunk = use_graph, chunk
         self.block_rows = int(hist[0].shape[0])
         self.graphs = {}
+        self._plans = {}
         self.timed = set()
         self.timing_error = None
         self.steps_run = 0
 
     def plan(self, n_steps):
-        return plan_region(n_steps, self.chunk, self.block_rows)
+        segs = self._plans.get(n_steps)                  # (a 100-microsecond region should not pay for re-planning itself)
+        if segs is None:
+            segs = self._plans[n_steps] = plan_region(n_steps, self.chunk, self.block_rows)
+        return segs
 
     def prepare(self, n_steps, timing=False):
         """capture the graphs a region of n_steps needs; timing=True: a region that is ONE graph carries event-record
