@@ -493,26 +493,15 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
     uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
-#ifdef AQUA_SS_SYNTH
-    const bool valid0 = static_cast<int64_t>(off) < rem;
-#endif
     constexpr uint32_t own_reset_mask = 0;
     if (RESTART && a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
-#ifdef AQUA_SS_SYNTH
-        // TIMING EXPERIMENT: a synthetic restart set of the usual density that does not depend on the state (the worlds
-        // that really finish keep stepping), so that builds which drop a piece of the restart keep their dynamics
-        const uint32_t synth = (valid0 && ((static_cast<uint32_t>(tile) + off) * 2654435761u + static_cast<uint32_t>(tick) * 40503u) % 54u == 0u) ? 1u : 0u;
-        if (synth) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off);
-        skip_mask = synth;
-#else
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if (done_mask & (1u << j)) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off + j);
         }
         skip_mask = done_mask;
-#endif
         AQUA_STAMP(4);      // outputs stored, list appended
         __syncthreads();
         AQUA_STAMP(5);      // barrier passed
@@ -525,20 +514,12 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             const uint32_t i = list[active ? q : 0];
             const uint64_t world = static_cast<uint64_t>(a.env_offset + tile) + i;
             EnvState e;
-#ifdef AQUA_SS_NOARITH
-            e.x = 50.0f + static_cast<float>(world & 15u); e.y = 50.0f; e.th = 0.0f; e.gx = 20.0f; e.gy = 80.0f; e.wx = 0.0f; e.wy = 0.0f; e.t = 0;
-#else
             if constexpr (QUICK == QUICK_ALWAYS)
                 e = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
                                                             k.K, k.obst, nullptr, k.quick, k.Kc);
             else
                 e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
-#endif
-#ifdef AQUA_SS_NOSTORE
-            if (active && (lane & (RESET_GROUP - 1)) == 0 && e.x == 12345.0f) {
-#else
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
-#endif
                 st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
                 st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
                 st1(row0 + 5 * ld + i, e.wx); st1(row0 + 6 * ld + i, e.wy);
