@@ -49,17 +49,18 @@ class DoneMaskExchange(object):
     [world][steps][words].  words must be the same on every rank (pad the last shard).
 
     kind="rccl" (default, what BASELINE.json's north_star names): torch.distributed.all_gather_into_tensor -- RCCL over
-        xGMI on device tensors, queued on a private side stream behind an event of the producing stream; gloo on CPU
-        tensors, synchronously.  RCCL's kernel runs on the compute units: one rank already pays 18-21 % of the step
-        stream for it (profiles/r02/exchange_overhead_one_rank.txt).
+        xGMI on device tensors, on a private side stream; gloo on CPU tensors, synchronously.
     kind="ipc": no collective kernel.  Every rank owns a receive buffer (include/aqua_hip.h aqua_ipc_*), the ranks exchange
         its 64-byte handle ONCE over the process group and map each other's buffers; a block is published as world - 1
         asynchronous device-to-device copies (one side stream per peer, so the copies of a block use different links)
-        plus a local copy, all behind an event of the producing stream.  copy_engine: "waves" = a short kernel of
-        single-wavefront workgroups, "dma" = hipMemcpyAsync (the copy engines over xGMI: nothing on the compute units),
-        "auto" (default) = waves into the own buffer, dma into the peers'.  There is no per-block handshake:
-        a rank may publish at most `slots` blocks between two fence() calls, and what the OTHER ranks sent is complete in
-        gathered[slot] after the next fence() (finish() + barrier: bench.py's region boundary).
+        plus a local copy.  copy_engine: "waves" = a short kernel of single-wavefront workgroups, "dma" = hipMemcpyAsync
+        (the copy engines over xGMI: nothing on the compute units), "auto" (default) = waves into the own buffer, dma
+        into the peers'.  There is no per-block handshake: a rank may publish at most `slots` blocks between two
+        fence() calls, and what the OTHER ranks sent is complete in gathered[slot] after the next fence() (finish() +
+        barrier: bench.py's region boundary).  Setting it up and probing it are collective decisions (_agree()).
+    (Round 2 measured 18-21 % of the step stream for the RCCL gather on one rank and blamed RCCL's workgroups; the cost was
+    the side stream's device-side wait on the step stream, which every transport shared: with the host-side pump below
+    one rank pays 0.3-1.7 % for either kind, profiles/r03/exchange_overhead_one_rank.txt.)
     Either kind: the step stream never waits for the exchange, except before it overwrites a source buffer whose last
     copy has not been read yet (wait_source) -- and no stream of the device ever waits for the step stream: the copies
     are queued by a pump thread once the block's event has completed (see gather_async)."""
