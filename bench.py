@@ -435,11 +435,11 @@ def main(argv=None):
     from aquaticgymenv_amd.sharded import DoneMaskExchange
 
     one_gpu = args.ranks_on_one_gpu
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL, mapped buffers): before the first HIP call
     dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     distributed = world > 1 or "RANK" in os.environ
     if distributed:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if one_gpu:
             dist.init_process_group("gloo")              # RCCL refuses two ranks on one device; gloo carries the barriers
         else:
