@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 A_DISCRETE = 62      # algorithmic bytes per world-step, SURVEY.md 8(d): 33 read + 29 written
 A_CONTINUOUS = 69
 HBM_PEAK_GBPS = 8000.0
+HBM_COPY_GBPS = 6290.0   # measured float4 copy (MI355X_MICROARCH.md chip table): SURVEY.md 8(d) asks for this fraction too
 CHUNK = 100          # steps per captured HIP graph (at most)
 GATHER_EVERY = 5     # chunks per done-mask block: one [GATHER_EVERY * CHUNK][words] all-gather per block (N > 1)
 REGIONS = 5          # timed regions; the median is reported
@@ -562,7 +563,8 @@ def main(argv=None):
                        "process_group": (("gloo (ranks share cuda:0: rehearsal, timings meaningless)" if one_gpu else "nccl (RCCL)")
                                          if distributed else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
                          "launch_us_regions": [e * 1e3 / args.steps for e in events],
                          "launch_us_events": "stream",
