@@ -33,6 +33,29 @@ except Exception:                      # pragma: no cover - depends on the envir
 INFO_KEYS = ("Termination.collided", "Termination.time", "Termination.success")
 
 
+def space_types(gym_module=None):
+    """(Box, Discrete): classic gym's own classes when gym is importable -- so that `isinstance(env.action_space,
+    gym.spaces.Discrete)` in gym-side code holds, as it does for the reference (aqua.py:30-52) -- else the look-alikes of
+    aquaticgymenv_amd/spaces.py (the build image has no gym)."""
+    gym_module = _gym if gym_module is None else gym_module
+    try:
+        return gym_module.spaces.Box, gym_module.spaces.Discrete
+    except Exception:
+        return spaces.Box, spaces.Discrete
+
+
+def make_space(cls, *args, seed=None, **kwargs):
+    """cls(*args, **kwargs) seeded with `seed`: newer gym and the look-alikes take seed= in the constructor, gym 0.17-0.21
+    (the reference's era) have a .seed() method instead"""
+    try:
+        return cls(*args, seed=seed, **kwargs)
+    except TypeError:
+        space = cls(*args, **kwargs)
+        if seed is not None and hasattr(space, "seed"):
+            space.seed(seed)
+        return space
+
+
 class _LazyInfo(dict):
     """info dict of a batched step: the three flags are produced from the term codes on first access."""
 
@@ -70,16 +93,17 @@ class AquaEnv(_EnvBase):
         self.wave_speed_variance = 0.001 * self.has_waves
         self.time_limit = TIME_LIMIT
         self.tau = 1
+        Box, Discrete = space_types()
         if self.continuous:
-            self.action_space = spaces.Box(self.motor_min_thrust, self.motor_max_thrust, shape=[2], dtype=np.float64,
+            self.action_space = make_space(Box, self.motor_min_thrust, self.motor_max_thrust, shape=[2], dtype=np.float64,
                                            seed=seed)
         else:
             self.actions = [(0.2, 0.5), (0.5, 0.2), (0.5, 0.5)]      # left, right, straight (aqua.py:33-42)
-            self.action_space = spaces.Discrete(len(self.actions), seed=seed)
-        self.observation_space = spaces.Box(np.array([0, 0, -np.pi, 0, 0]),
+            self.action_space = make_space(Discrete, len(self.actions), seed=seed)
+        self.observation_space = make_space(Box, np.array([0, 0, -np.pi, 0, 0]),
                                             np.array([self.world_size, self.world_size, np.pi, self.world_size,
                                                       self.world_size]), dtype=np.float64, seed=seed)
-        self.wave_space = spaces.Box(self.wave_min_speed, self.wave_max_speed, shape=[2], dtype=np.float64, seed=seed)
+        self.wave_space = make_space(Box, self.wave_min_speed, self.wave_max_speed, shape=[2], dtype=np.float64, seed=seed)
         rows = presets.rows_from(obstacles)
         self.obstacles = presets.as_reference_list(rows)
         self.core = BatchedAqua(self.num_envs, obstacles=rows, waves=waves, random_boat=random_boat,

@@ -307,3 +307,37 @@ def test_spaces_lookalikes():
     assert act.low.tolist() == [0.2, 0.2] and act.contains(np.array([0.2, 0.5])) and not act.contains(np.array([0.1, 0.3]))
     d = spaces.Discrete(3, seed=2)
     assert d.n == 3 and all(0 <= d.sample() < 3 for _ in range(20)) and d.contains(2) and not d.contains(3)
+
+
+def test_facade_uses_gyms_own_spaces_when_gym_is_there():
+    """the reference's spaces ARE gym.spaces.Box / Discrete (aqua.py:30-52); the facade uses gym's classes when gym is
+    importable and its own look-alikes otherwise (the build image has no gym).  Old gym (the reference's era) takes no
+    seed= in the constructor: the space is seeded through .seed() then."""
+    import types
+    from aquaticgymenv_amd import spaces as own
+    from gym_aqua.envs import aqua as facade
+
+    class OldBox(object):                                    # gym 0.17: no seed keyword
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.args, self.seeded = (low, high, shape, dtype), None
+
+        def seed(self, seed=None):
+            self.seeded = seed
+
+    class OldDiscrete(object):
+        def __init__(self, n):
+            self.n, self.seeded = n, None
+
+        def seed(self, seed=None):
+            self.seeded = seed
+
+    gym_like = types.SimpleNamespace(spaces=types.SimpleNamespace(Box=OldBox, Discrete=OldDiscrete))
+    assert facade.space_types(gym_like) == (OldBox, OldDiscrete)
+    assert facade.space_types(types.SimpleNamespace()) == (own.Box, own.Discrete)            # no gym.spaces: look-alikes
+    assert facade.space_types(None) == ((own.Box, own.Discrete) if facade._gym is None else facade.space_types(facade._gym))
+    d = facade.make_space(OldDiscrete, 3, seed=7)
+    assert d.n == 3 and d.seeded == 7
+    b = facade.make_space(OldBox, 0.2, 0.5, shape=[2], dtype=np.float64, seed=None)
+    assert b.args[2] == [2] and b.seeded is None
+    mine = facade.make_space(own.Discrete, 3, seed=5)                                         # seed= in the constructor
+    assert mine.n == 3 and 0 <= mine.sample() < 3
