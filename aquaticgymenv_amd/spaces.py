@@ -1,8 +1,8 @@
 """Minimal stand-ins for the two gym space classes the reference exposes on its env
 (gym_aqua/envs/aqua.py:30,43,46,52): callers read .shape/.low/.high/.n and call .sample()/.contains()
 (main/impl/dqn.py:99-100, main/impl/utils.py:19-21, main/testing/test_random.py:20).
-The facade always uses these (also when gym is importable): they accept everything the reference's callers do with
-the real classes, and the env works the same with or without gym installed."""
+The facade uses them when classic gym is NOT importable (the build image; with gym present it uses gym's own classes,
+gym_aqua/envs/aqua.py space_types()): they accept everything the reference's callers do with the real classes."""
 import numpy as np
 
 
