@@ -530,6 +530,17 @@ def main(argv=None):
     if not (x_after != x_before):
         raise RuntimeError("the worlds did not move during the timed regions (x checksum %r -> %r)" % (x_before, x_after))
     ended = episodes_ended(hist, segs, np)
+    exchange_check = None
+    if exchange is not None and segs:
+        # the last block as it arrived: this rank's own copy must BE its done-mask buffer, and the other ranks' blocks must
+        # show episodes ending there too (after the closing barrier every block of the region is in place everywhere)
+        last_slot = (exchange._slot - 1) % exchange.slots
+        got = exchange.gathered[last_slot]
+        peers = [int(popcount_words(got[r].cpu().numpy(), np)) for r in range(ranks_seen) if r != rank]
+        exchange_check = {"own_block_intact": bool(torch.equal(got[rank], hist[segs[-1][0]])),
+                          "episodes_in_peer_blocks": peers}
+        if not exchange_check["own_block_intact"]:
+            raise RuntimeError("rank %d: the done-mask block it received from itself differs from the block it sent" % rank)
 
     result = None
     if rank == 0:
@@ -573,7 +584,8 @@ def main(argv=None):
                          "note": "launch_us = HIP-event time of a timed region / its launches, median region, inter-kernel "
                                  "boundaries included; the events are recorded on the launch stream around the region's "
                                  "graph launches.  Kernel-only duration: profiles/"},
-            "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended},
+            "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended,
+                       "done_mask_exchange_last_block": exchange_check},
         }
         if cpu is not None:
             result["cpu_baseline"], result["cpu_baseline_1core"], result["cpu_baseline_c"] = cpu

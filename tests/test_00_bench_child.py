@@ -102,6 +102,9 @@ def test_bench_launches_its_own_ranks():
     cfg = r["config"]
     assert cfg["done_mask_exchange"] is True and cfg["done_mask_exchange_kind"] == "ipc"
     assert cfg["global_worlds"] == 2 * 65536 and cfg["parallelism"] == "range-partition x2"
+    check = r["sanity"]["done_mask_exchange_last_block"]
+    assert check["own_block_intact"] is True and len(check["episodes_in_peer_blocks"]) == 1
+    assert check["episodes_in_peer_blocks"][0] > 0, "rank 1's done masks must have arrived at rank 0"
     assert "cpu_baseline" not in r
 
 
