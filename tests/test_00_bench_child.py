@@ -73,6 +73,21 @@ def test_bench_odd_step_counts_in_a_child_process():
 
 
 @pytest.mark.gpu
+def test_bench_diagnostic_flags_in_a_child_process():
+    """the flags the round's measurements were taken with: event-record nodes beside the stream events, the copy engines for
+    the done-mask copies, a pause between regions, the eager launch loop"""
+    r = _run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--force-exchange",
+              "--copy-engine", "dma", "--graph-node-events", "--settle-us", "100"])
+    _check_line(r, 20, 5)
+    nodes = r["roofline"]["launch_us_graph_nodes_regions"]
+    assert len(nodes) == 5 and all(v and v > 1.0 for v in nodes)
+    assert r["config"]["done_mask_exchange_kind"] == "ipc" and r["config"]["done_mask_copy_engine"] == "dma"
+    assert r["sanity"]["done_mask_exchange_last_block"]["own_block_intact"] is True
+    r = _run([sys.executable, "bench.py", "--steps", "30", "--warmup", "3", "--no-cpu-baseline", "--eager"])
+    assert r["config"]["launch"] == "eager" and r["steps"] == 30 and r["sanity"]["steps_queued"] == 3 + 5 * 30
+
+
+@pytest.mark.gpu
 def test_bench_under_torch_distributed_run_executes_the_rccl_branch():
     """one rank under torch.distributed.run: init_process_group("nccl"), the barriers, the MAX all-reduce of the region
     times and the done-mask all_gather_into_tensor (RCCL, side stream, double buffer) all execute on the device.
