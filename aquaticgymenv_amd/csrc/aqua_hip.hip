@@ -78,7 +78,7 @@ struct StepArgs {
 // the loads of a lane are issued back to back as global_load_dword{,x2,x4} v, voffset, s[base].
 // Stores carry agent scope (`global_store ... sc1`): they are written through the XCD's L2 while the kernel runs, so the
 // end-of-kernel release has almost nothing left to write back (-0.3 us per launch; system scope: the same; non-temporal:
-// -0.1; hinted loads: slower -- DESIGN.md section 5.3).
+// -0.1; hinted loads: slower -- profiles/LOG.md).
 template <typename T>
 __device__ __forceinline__ T ld1(const T* p)
 {
@@ -87,7 +87,25 @@ __device__ __forceinline__ T ld1(const T* p)
 template <typename T>
 __device__ __forceinline__ void st1(T* p, T v)
 {
+#ifdef AQUA_ST1_PLAIN                    // (timing experiment: every store left to the L2's write-back)
+    *p = v;
+#else
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// The packed done mask: one 8-byte ballot word per wavefront.  Left to a plain store, the words stay dirty in the XCD's
+// L2 and the end-of-kernel release writes them back while nothing else runs: 0.15-0.2 us of a 5 us launch at 262 144
+// worlds (5.01 -> 4.86 us next-step, 6.45 -> 6.33 same-step, 4.06 -> 3.87 without restarts; profiles/r03/ab_done_word.txt).
+// Written through instead, every word is a partial-line write of its own; from a couple of million worlds on that costs
+// more (nothing at 1 M, +0.8 % at 2.1 M and 4.2 M, +1 % at 16.7 M) than the write-back of lines the L2 has merged, so the
+// scope follows the batch size.  (The fused rollouts' per-step reward/term stores stay plain: written through, the
+// per-world fused rollout without restarts went from 1.73 to 2.05 us per step, the others did not move.)
+constexpr int64_t DONE_WORD_WRITE_THROUGH_MAX_WORLDS = int64_t(1) << 20;
+__device__ __forceinline__ void store_done_word(uint64_t* p, uint64_t v, int64_t n_worlds)
+{
+    if (n_worlds <= DONE_WORD_WRITE_THROUGH_MAX_WORLDS) st1(p, v);
+    else *p = v;
 }
 
 // uniform base + zero-extended 32-bit BYTE offset: the form the backend turns into `global_load v, voffset, s[base]`
@@ -124,7 +142,7 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            if (static_cast<int64_t>(off) + j < rem) p[off + j] = v[j];
+            if (static_cast<int64_t>(off) + j < rem) st1(p + off + j, v[j]);
     }
 }
 
@@ -322,7 +340,7 @@ __device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, u
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done_mask & 1u);
         const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u)) / 64;
-        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) store_done_word(a.done_bits + word, b, a.N);
     }
 }
 
@@ -546,9 +564,9 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = off + j;
             if (!(skip_mask & (1u << j)) && static_cast<int64_t>(i) < rem) {
-                row0[0 * ld + i] = x[j]; row0[1 * ld + i] = y[j]; row0[2 * ld + i] = th[j];
-                row0[5 * ld + i] = wx[j]; row0[6 * ld + i] = wy[j];
-                trow[i] = t[j];
+                st1(row0 + 0 * ld + i, x[j]); st1(row0 + 1 * ld + i, y[j]); st1(row0 + 2 * ld + i, th[j]);
+                st1(row0 + 5 * ld + i, wx[j]); st1(row0 + 6 * ld + i, wy[j]);
+                st1(trow + i, t[j]);
                 write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j]);
             }
         }
@@ -592,8 +610,8 @@ __device__ __forceinline__ void tick_housekeeping()
         uint64_t* const bump_to = reinterpret_cast<uint64_t*>(word(offsetof(StepArgs, tick_bump_to)));
         if (copy_to != nullptr || bump_to != nullptr) {
             const uint64_t base = *reinterpret_cast<const uint64_t*>(word(offsetof(StepArgs, tick_base)));
-            if (copy_to != nullptr) *copy_to = base;
-            if (bump_to != nullptr) *bump_to = base + word(offsetof(StepArgs, tick_bump));
+            if (copy_to != nullptr) st1(copy_to, base);
+            if (bump_to != nullptr) st1(bump_to, base + word(offsetof(StepArgs, tick_bump)));
         }
     }
 }
@@ -889,7 +907,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done);
         const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
-        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = b;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) store_done_word(a.done_bits + word, b, a.N);
     }
     if (live) {                                        // pending worlds are written by the re-seeding blocks
         st_at(row0 + 0 * ld, s4, e.x); st_at(row0 + 1 * ld, s4, e.y); st_at(row0 + 2 * ld, s4, e.th);
@@ -1211,7 +1229,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     const uint64_t done_ballot = __ballot(done);
     if (a.done_bits != nullptr) {
         const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
-        if (lane == 0 && word < ((a.N + 63) >> 6)) a.done_bits[word] = done_ballot;
+        if (lane == 0 && word < ((a.N + 63) >> 6)) store_done_word(a.done_bits + word, done_ballot, a.N);
     }
     if constexpr ((RESTART || MODE == TABLES_NEXT_STEP_TILE) && KREG > 0) {
         // restart inside the tile, rows handed over through LDS (HandoffShared above)
