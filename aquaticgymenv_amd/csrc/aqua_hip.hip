@@ -84,15 +84,31 @@ __device__ __forceinline__ T ld1(const T* p)
 {
     return *p;
 }
+// `wb` (a constant false everywhere but in the kernels of large batches, see STORE_WB_* below): leave the store to the L2's
+// write-back instead.
 template <typename T>
-__device__ __forceinline__ void st1(T* p, T v)
+__device__ __forceinline__ void st1(T* p, T v, bool wb = false)
 {
 #ifdef AQUA_ST1_PLAIN                    // (timing experiment: every store left to the L2's write-back)
     *p = v;
 #else
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wb) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+
+// Written through, a store costs the launch nothing at its end, and that is what counts while a step is a few
+// microseconds long.  In a batch of millions of worlds the end of the launch no longer matters and the L2 merging the
+// partial lines of a tile -- the stepping wavefront's masked rows and the restarted worlds' 4-byte stores -- does:
+// st1() as a plain store against agent scope, us per step (profiles/r03/ab_plain_stores.txt; @2 next-step, @1 same-step):
+//     worlds     524 288   1 M     2.1 M   4.2 M   8.4 M   12.6 M   16.7 M
+//     @2 plain    8.90    13.18    25.3    52.5    91.1    147.3    207.6
+//     @2 agent    8.14    12.98    26.8    65.7    94.1    148.3    197.7
+//     @1 plain   11.30      -      34.4    69.4   129.0    189.1    252.1
+//     @1 agent   10.58      -      35.8    72.7   144.0    213.0    285.8
+// (without restarts the two are within 3 % of each other from 8.4 M on and agent scope wins below: it stays.)
+constexpr int64_t STORE_WB_SAME_STEP_MIN = int64_t(1) << 21;                                // same-step restart: from here on
+constexpr int64_t STORE_WB_NEXT_STEP_MIN = int64_t(1) << 21, STORE_WB_NEXT_STEP_MAX = 3 * (int64_t(1) << 22);   // next-step: in between
 
 // The packed done mask: one 8-byte ballot word per wavefront.  Left to a plain store, the words stay dirty in the XCD's
 // L2 and the end-of-kernel release writes them back while nothing else runs: 0.15-0.2 us of a 5 us launch at 262 144
@@ -116,9 +132,9 @@ __device__ __forceinline__ T ld_at(const T* base, uint32_t byte_off)
     return ld1(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
 }
 template <typename T>
-__device__ __forceinline__ void st_at(T* base, uint32_t byte_off, T v)
+__device__ __forceinline__ void st_at(T* base, uint32_t byte_off, T v, bool wb = false)
 {
-    st1(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+    st1(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v, wb);
 }
 
 template <int VEC, bool FULL, typename T>
@@ -134,15 +150,15 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, 
 }
 
 template <int VEC, bool FULL, typename T>
-__device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64_t rem, const T (&v)[VEC])
+__device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64_t rem, const T (&v)[VEC], bool wb = false)
 {
     static_assert(VEC == 1, "one world per lane");
     if constexpr (FULL) {
-        st1(p + off, v[0]);
+        st1(p + off, v[0], wb);
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            if (static_cast<int64_t>(off) + j < rem) st1(p + off + j, v[j]);
+            if (static_cast<int64_t>(off) + j < rem) st1(p + off + j, v[j], wb);
     }
 }
 
@@ -299,42 +315,44 @@ __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_
 
 // Optional fused epilogue: the observation as main/impl/utils.py:15-33 (AquaStateNormalizer) hands it to the DQN --
 // obs / (high - low) with 0.5 added to the angle: x/100, y/100, theta/(2 pi) + 0.5, gx/100, gy/100.
-__device__ __forceinline__ void write_norm(const StepArgs& a, int64_t i, float x, float y, float th, float gx, float gy)
+__device__ __forceinline__ void write_norm(const StepArgs& a, int64_t i, float x, float y, float th, float gx, float gy,
+                                           bool wb = false)
 {
     if (a.obs_norm == nullptr) return;
     float* const o = a.obs_norm + i;
-    st1(o + 0 * a.ld, x * 0.01f);
-    st1(o + 1 * a.ld, y * 0.01f);
-    st1(o + 2 * a.ld, fmaf(th, 0.15915494309189535f, 0.5f));
-    st1(o + 3 * a.ld, gx * 0.01f);
-    st1(o + 4 * a.ld, gy * 0.01f);
+    st1(o + 0 * a.ld, x * 0.01f, wb);
+    st1(o + 1 * a.ld, y * 0.01f, wb);
+    st1(o + 2 * a.ld, fmaf(th, 0.15915494309189535f, 0.5f), wb);
+    st1(o + 3 * a.ld, gx * 0.01f, wb);
+    st1(o + 4 * a.ld, gy * 0.01f, wb);
 }
 
 // the same rows written as uniform row base + the lane's 32-bit byte offset (st_at)
 __device__ __forceinline__ void write_norm_at(const StepArgs& a, int64_t tile, uint32_t byte_off, float x, float y, float th,
-                                              float gx, float gy)
+                                              float gx, float gy, bool wb = false)
 {
     if (a.obs_norm == nullptr) return;
     float* const o = a.obs_norm + tile;
-    st_at(o + 0 * a.ld, byte_off, x * 0.01f);
-    st_at(o + 1 * a.ld, byte_off, y * 0.01f);
-    st_at(o + 2 * a.ld, byte_off, fmaf(th, 0.15915494309189535f, 0.5f));
-    st_at(o + 3 * a.ld, byte_off, gx * 0.01f);
-    st_at(o + 4 * a.ld, byte_off, gy * 0.01f);
+    st_at(o + 0 * a.ld, byte_off, x * 0.01f, wb);
+    st_at(o + 1 * a.ld, byte_off, y * 0.01f, wb);
+    st_at(o + 2 * a.ld, byte_off, fmaf(th, 0.15915494309189535f, 0.5f), wb);
+    st_at(o + 3 * a.ld, byte_off, gx * 0.01f, wb);
+    st_at(o + 4 * a.ld, byte_off, gy * 0.01f, wb);
 }
 
 // reward / term / packed done bits of one wavefront's worlds
 template <int VEC>
 __device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, bool full,
-                                              const float (&rew)[VEC], const uint8_t (&code)[VEC], uint32_t done_mask)
+                                              const float (&rew)[VEC], const uint8_t (&code)[VEC], uint32_t done_mask,
+                                              bool wb = false)
 {
     const int lane = threadIdx.x & 63;
     if (full) {
-        store_row<VEC, true>(a.reward + tile, off, rem, rew);
-        store_row<VEC, true>(a.term + tile, off, rem, code);
+        store_row<VEC, true>(a.reward + tile, off, rem, rew, wb);
+        store_row<VEC, true>(a.term + tile, off, rem, code, wb);
     } else {
-        store_row<VEC, false>(a.reward + tile, off, rem, rew);
-        store_row<VEC, false>(a.term + tile, off, rem, code);
+        store_row<VEC, false>(a.reward + tile, off, rem, rew, wb);
+        store_row<VEC, false>(a.term + tile, off, rem, code, wb);
     }
     static_assert(VEC == 1, "one world per lane: the wavefront's ballot IS its done word");
     if (a.done_bits != nullptr) {
@@ -420,7 +438,7 @@ __device__ __forceinline__ void fold_actions(const int64_t (&araw)[VEC], int (&a
 // SMALL_TABLE): the obstacle look and the re-seeding read it, and nothing walks the rows outside the rare paths.
 // RESTART == false: the launch never restarts a world (auto_reset 0, the reference's own step()): no list, no
 // barrier, no re-seeding code in the kernel.  RESTART == true serves both (the run-time a.auto_reset decides).
-template <int AK, bool SMALL, bool RESTART>
+template <int AK, bool SMALL, bool RESTART, bool WB = false>
 __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
                                           TileShared& sh)
 {
@@ -507,7 +525,8 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
         done_mask |= (code[j] != 0 && static_cast<int64_t>(off) + j < rem) ? (1u << j) : 0u;
-    store_outputs<VEC>(a, tile, off, rem, full, rew, code, done_mask);
+    constexpr bool wb = WB;                              // the stores of this tile: left to the L2's write-back, or written through
+    store_outputs<VEC>(a, tile, off, rem, full, rew, code, done_mask, wb);
 
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
     uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
@@ -538,36 +557,36 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
             else
                 e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
-                st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
-                st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
-                st1(row0 + 5 * ld + i, e.wx); st1(row0 + 6 * ld + i, e.wy);
-                st1(trow + i, e.t);
-                write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy);
+                st1(row0 + 0 * ld + i, e.x, wb); st1(row0 + 1 * ld + i, e.y, wb); st1(row0 + 2 * ld + i, e.th, wb);
+                st1(row0 + 3 * ld + i, e.gx, wb); st1(row0 + 4 * ld + i, e.gy, wb);
+                st1(row0 + 5 * ld + i, e.wx, wb); st1(row0 + 6 * ld + i, e.wy, wb);
+                st1(trow + i, e.t, wb);
+                write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy, wb);
             }
         }
     }
     AQUA_STAMP(6);          // group re-seeding done
 
     if (skip_mask == 0 && own_reset_mask == 0 && full) {
-        store_row<VEC, true>(row0 + 0 * ld, off, rem, x);
-        store_row<VEC, true>(row0 + 1 * ld, off, rem, y);
-        store_row<VEC, true>(row0 + 2 * ld, off, rem, th);
-        store_row<VEC, true>(row0 + 5 * ld, off, rem, wx);
-        store_row<VEC, true>(row0 + 6 * ld, off, rem, wy);
-        store_row<VEC, true>(trow, off, rem, t);
+        store_row<VEC, true>(row0 + 0 * ld, off, rem, x, wb);
+        store_row<VEC, true>(row0 + 1 * ld, off, rem, y, wb);
+        store_row<VEC, true>(row0 + 2 * ld, off, rem, th, wb);
+        store_row<VEC, true>(row0 + 5 * ld, off, rem, wx, wb);
+        store_row<VEC, true>(row0 + 6 * ld, off, rem, wy, wb);
+        store_row<VEC, true>(trow, off, rem, t, wb);
         if (a.obs_norm != nullptr) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) write_norm(a, tile + off + j, x[j], y[j], th[j], gx[j], gy[j]);
+            for (int j = 0; j < VEC; ++j) write_norm(a, tile + off + j, x[j], y[j], th[j], gx[j], gy[j], wb);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const uint32_t i = off + j;
             if (!(skip_mask & (1u << j)) && static_cast<int64_t>(i) < rem) {
-                st1(row0 + 0 * ld + i, x[j]); st1(row0 + 1 * ld + i, y[j]); st1(row0 + 2 * ld + i, th[j]);
-                st1(row0 + 5 * ld + i, wx[j]); st1(row0 + 6 * ld + i, wy[j]);
-                st1(trow + i, t[j]);
-                write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j]);
+                st1(row0 + 0 * ld + i, x[j], wb); st1(row0 + 1 * ld + i, y[j], wb); st1(row0 + 2 * ld + i, th[j], wb);
+                st1(row0 + 5 * ld + i, wx[j], wb); st1(row0 + 6 * ld + i, wy[j], wb);
+                st1(trow + i, t[j], wb);
+                write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j], wb);
             }
         }
     }
@@ -616,7 +635,7 @@ __device__ __forceinline__ void tick_housekeeping()
     }
 }
 
-template <int AK, bool SMALL, bool RESTART>
+template <int AK, bool SMALL, bool RESTART, bool WB = false>
 __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const StepArgs a)
 {
     __shared__ TileShared sh;
@@ -625,7 +644,7 @@ __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const StepArgs a)
     const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     if (RESTART && a.auto_reset) __syncthreads();
     const uint64_t tick = launch_tick(a);
-    step_tile<AK, SMALL, RESTART>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
+    step_tile<AK, SMALL, RESTART, WB>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
 }
 
 // ------------------------------------------------------------------ one launch per step, next-step restart
@@ -664,6 +683,8 @@ static_assert(NS_SCAN % NS_TILE == 0, "a re-seeding block covers whole stepping 
 // 1 M 14.6 vs 14.3, 262 144 5.60 vs 5.55
 constexpr int64_t NS_INTERLEAVE_MIN = 1 << 19;
 
+static_assert(STORE_WB_NEXT_STEP_MIN >= NS_INTERLEAVE_MIN, "only the interleaved layout has a write-back kernel");
+
 __device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static_cast<int32_t>(tick & 1u); }
 __device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
 
@@ -676,7 +697,7 @@ struct NsReseedShared {
 
 // SMALL_TABLE: the launch has at most NS_TABLE_ROWS obstacles (decided on the host: one kernel per case keeps the
 // code each launch has to fetch short -- the instruction cache starts every launch cold)
-template <bool SMALL_TABLE>
+template <bool SMALL_TABLE, bool WB>
 __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block, NsReseedShared& sh)
 {
     __builtin_amdgcn_s_setprio(3);                      // the longest chain of the launch: issue first
@@ -749,11 +770,12 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
         else
             e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
         if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
-            st1(row0 + 0 * ld + i, e.x); st1(row0 + 1 * ld + i, e.y); st1(row0 + 2 * ld + i, e.th);
-            st1(row0 + 3 * ld + i, e.gx); st1(row0 + 4 * ld + i, e.gy);
-            st1(row0 + 5 * ld + i, e.wx); st1(row0 + 6 * ld + i, e.wy);
-            st1(trow + i, restart_code(tick));
-            write_norm(a, base + i, e.x, e.y, e.th, e.gx, e.gy);
+            constexpr bool wb = WB;
+            st1(row0 + 0 * ld + i, e.x, wb); st1(row0 + 1 * ld + i, e.y, wb); st1(row0 + 2 * ld + i, e.th, wb);
+            st1(row0 + 3 * ld + i, e.gx, wb); st1(row0 + 4 * ld + i, e.gy, wb);
+            st1(row0 + 5 * ld + i, e.wx, wb); st1(row0 + 6 * ld + i, e.wy, wb);
+            st1(trow + i, restart_code(tick), wb);
+            write_norm(a, base + i, e.x, e.y, e.th, e.gx, e.gy, wb);
         }
     }
     AQUA_RTSTAMP(2);
@@ -794,7 +816,7 @@ __device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, in
 
 // INTERLEAVE: the grid layout (chosen on the host by batch size, like SMALL_TABLE: one kernel per case keeps the SGPR
 // file of the one-round case -- the benchmarked one -- exactly as tight as it was)
-template <int AK, bool SMALL_TABLE, bool INTERLEAVE>
+template <int AK, bool SMALL_TABLE, bool INTERLEAVE, bool WB = false>
 __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void step_ns_kernel(const StepArgs a)
 {
     __shared__ NsReseedShared sh;
@@ -809,7 +831,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
     if (reseed_role) {
 #ifndef AQUA_NS_NOWORK                       // (timing experiment: what the re-seeding blocks cost the launch)
-        ns_reseed_block<SMALL_TABLE>(a, role_index, sh);
+        ns_reseed_block<SMALL_TABLE, WB>(a, role_index, sh);
 #endif
         return;
     }
@@ -900,9 +922,10 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     // used, and there it is the store's own SGPR base + 32-bit VGPR offset addressing: no instruction at all.
     uint32_t s4 = o4, s1 = o;
     asm volatile("" : "+v"(s4), "+v"(s1));
+    constexpr bool wb = WB;                             // batches of millions of worlds only (STORE_WB_*)
     if (valid) {
-        st_at(a.reward + tile, s4, rew);
-        st_at(a.term + tile, s1, static_cast<uint8_t>(code));
+        st_at(a.reward + tile, s4, rew, wb);
+        st_at(a.term + tile, s1, static_cast<uint8_t>(code), wb);
     }
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done);
@@ -910,14 +933,14 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
         if (lane == 0 && word < ((a.N + 63) >> 6)) store_done_word(a.done_bits + word, b, a.N);
     }
     if (live) {                                        // pending worlds are written by the re-seeding blocks
-        st_at(row0 + 0 * ld, s4, e.x); st_at(row0 + 1 * ld, s4, e.y); st_at(row0 + 2 * ld, s4, e.th);
-        st_at(row0 + 5 * ld, s4, e.wx); st_at(row0 + 6 * ld, s4, e.wy);
+        st_at(row0 + 0 * ld, s4, e.x, wb); st_at(row0 + 1 * ld, s4, e.y, wb); st_at(row0 + 2 * ld, s4, e.th, wb);
+        st_at(row0 + 5 * ld, s4, e.wx, wb); st_at(row0 + 6 * ld, s4, e.wy, wb);
 #ifdef AQUA_NS_NOWORK
-        st_at(trow, s4, e.t);
+        st_at(trow, s4, e.t, wb);
 #else
-        st_at(trow, s4, done ? done_code(tick) : e.t);
+        st_at(trow, s4, done ? done_code(tick) : e.t, wb);
 #endif
-        write_norm_at(a, tile, s4, e.x, e.y, e.th, gx[0], gy[0]);
+        write_norm_at(a, tile, s4, e.x, e.y, e.th, gx[0], gy[0], wb);
     }
     AQUA_RTSTAMP(2);
 }
@@ -1811,10 +1834,13 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     const dim3 grid(grid_for(a.N, TILE_WORLDS, MAX_GRID)), block(TILE_WORLDS);
     const bool small = a.K > 0 && a.K <= QUICK_MAX;
     const bool plain = a.auto_reset == 0;               // no restart: no list, no barrier, no re-seeding code in the kernel
+    const bool wb = !plain && a.N >= STORE_WB_SAME_STEP_MIN;
 #define AQUA_STEP_LAUNCH(AK)                                                                                     \
     case AK:                                                                                                     \
         if (plain && small) hipLaunchKernelGGL((step_kernel<AK, true, false>), grid, block, 0, s, a);            \
         else if (plain) hipLaunchKernelGGL((step_kernel<AK, false, false>), grid, block, 0, s, a);               \
+        else if (small && wb) hipLaunchKernelGGL((step_kernel<AK, true, true, true>), grid, block, 0, s, a);     \
+        else if (wb) hipLaunchKernelGGL((step_kernel<AK, false, true, true>), grid, block, 0, s, a);             \
         else if (small) hipLaunchKernelGGL((step_kernel<AK, true, true>), grid, block, 0, s, a);                 \
         else hipLaunchKernelGGL((step_kernel<AK, false, true>), grid, block, 0, s, a);                           \
         break;
@@ -1837,6 +1863,7 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     StepArgs a = a0;
     a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
     const bool interleave = a.N >= NS_INTERLEAVE_MIN;
+    const bool wb = a.N >= STORE_WB_NEXT_STEP_MIN && a.N <= STORE_WB_NEXT_STEP_MAX;      // implies interleave
     const int64_t tiles = interleave ? (a.reseed_blocks + 7) / 8 * 8 * (NS_SCAN / NS_TILE + 1)
                                      : (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     if (tiles > MAX_GRID) return hipErrorInvalidValue;
@@ -1844,7 +1871,9 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     const bool small = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;
 #define AQUA_NS_LAUNCH(AK)                                                                           \
     case AK:                                                                                         \
-        if (small && interleave) hipLaunchKernelGGL((step_ns_kernel<AK, true, true>), grid, block, 0, s, a);        \
+        if (small && wb) hipLaunchKernelGGL((step_ns_kernel<AK, true, true, true>), grid, block, 0, s, a);          \
+        else if (wb) hipLaunchKernelGGL((step_ns_kernel<AK, false, true, true>), grid, block, 0, s, a);             \
+        else if (small && interleave) hipLaunchKernelGGL((step_ns_kernel<AK, true, true>), grid, block, 0, s, a);   \
         else if (small) hipLaunchKernelGGL((step_ns_kernel<AK, true, false>), grid, block, 0, s, a);                \
         else if (interleave) hipLaunchKernelGGL((step_ns_kernel<AK, false, true>), grid, block, 0, s, a);           \
         else hipLaunchKernelGGL((step_ns_kernel<AK, false, false>), grid, block, 0, s, a);                          \

@@ -320,6 +320,30 @@ def test_benchmarked_instantiation_against_oracle_at_benchmark_size(torch, oracl
     assert finished > n // 100 and restarted > n // 100, "the rollout must exercise the restart path"
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["same_step", "next_step"])
+def test_large_batch_store_policy_equals_its_shards(torch, mode):
+    """From 2 097 152 worlds on the restart kernels leave their stores to the L2's write-back (aqua_hip.hip, STORE_WB_*);
+    smaller batches write them through.  A world's trajectory depends on (seed, world index, tick) only, so one batch of
+    2 M worlds must equal, bit for bit, the same worlds stepped as shards of at most 262 144 (the oracle-checked kernels)."""
+    from aquaticgymenv_amd import presets
+    n, steps, shard = (1 << 21) + 1029, 8, 262144
+    whole = _make(torch, n, presets.BENCH8, seed=31, auto_reset=mode)
+    whole.reset()
+    w_rew, w_term = whole.rollout(steps, actions="random", keep_all=True)
+    ended = 0
+    for first in range(0, n, shard):
+        m = min(shard, n - first)
+        part = _make(torch, m, presets.BENCH8, seed=31, auto_reset=mode, env_offset=first)
+        part.reset()
+        p_rew, p_term = part.rollout(steps, actions="random", keep_all=True)
+        assert torch.equal(part.state[:, :m], whole.state[:, first:first + m])
+        assert torch.equal(part.time[:m], whole.time[first:first + m])
+        assert torch.equal(p_rew[:, :m], w_rew[:, first:first + m])
+        assert torch.equal(p_term[:, :m], w_term[:, first:first + m])
+        ended += int((p_term[:, :m] != 0).sum())
+    assert ended > n // 20, "the rollout must exercise the restart path"
+
+
 @pytest.mark.parametrize("mode,env_offset", [(1, 0), (2, 0), (2, 7)], ids=["same_step", "next_step", "next_step_odd_offset"])
 def test_sampled_actions_match_oracle_rollout(torch, oracle, mode, env_offset):
     """40 steps, discrete and continuous.  mode 1: finished worlds are re-seeded in the launch that finished them;
