@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64
@@ -22,7 +22,7 @@ SYMBOLS = (
     "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
     "aqua_rollout_tables_fused_f32",
     "aqua_ipc_buffer_create", "aqua_ipc_buffer_ptr", "aqua_ipc_buffer_handle", "aqua_ipc_buffer_destroy", "aqua_ipc_open",
-    "aqua_ipc_close", "aqua_copy_async", "aqua_copy_fanout_async",
+    "aqua_ipc_close", "aqua_copy_async", "aqua_copy_fanout_async", "aqua_rollout_events_f32",
 )
 IPC_HANDLE_BYTES = 64
 COPY_ENGINE_WAVES, COPY_ENGINE_DMA = 0, 1
@@ -59,6 +59,8 @@ def _load():
     lib.aqua_reset_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, vp, u64, u64, vp, vp]
     lib.aqua_rollout_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp, vp, vp,
                                      i64, vp, i64, vp, ci, ci, vp]
+    lib.aqua_rollout_events_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp, vp, vp,
+                                            i64, vp, i64, vp, ci, ci, vp, vp, vp]
     lib.aqua_rollout_fused_f32.argtypes = [pp, vp, ci, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64, u64, u64, vp,
                                            vp, vp, i64, ci, vp]
     lib.aqua_tick_advance.argtypes = [vp, u64, vp]
@@ -100,7 +102,8 @@ def _load():
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
                  "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
                  "aqua_rollout_tables_fused_f32", "aqua_ipc_buffer_create", "aqua_ipc_buffer_handle", "aqua_ipc_buffer_destroy",
-                 "aqua_ipc_open", "aqua_ipc_close", "aqua_copy_async", "aqua_copy_fanout_async"):
+                 "aqua_ipc_open", "aqua_ipc_close", "aqua_copy_async", "aqua_copy_fanout_async",
+                 "aqua_rollout_events_f32"):
         getattr(lib, name).restype = ci
     if lib.aqua_version() != ABI_VERSION:
         raise ImportError("libaqua_hip.so ABI %d != binding %d: rebuild" % (lib.aqua_version(), ABI_VERSION))

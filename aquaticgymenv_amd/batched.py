@@ -19,6 +19,62 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
+class LaunchEvents(object):
+    """Two HIP events for rollout(events=...): the first step launch's start and the last one's end, taken from the
+    kernels' own dispatch packets (no marker packets in the queue).  elapsed_ms() after the stream has been synchronised."""
+
+    def __init__(self):
+        self._handles = []
+        for _ in range(2):
+            e = ctypes.c_void_p()
+            rc = _capi.lib.aqua_event_create(ctypes.byref(e))
+            if rc:
+                self.close()
+                _capi.check(rc, "aqua_event_create")
+            self._handles.append(e)
+
+    @property
+    def start(self):
+        return self._handles[0]
+
+    @property
+    def stop(self):
+        return self._handles[1]
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float(0.0)
+        _capi.check(_capi.lib.aqua_event_elapsed_ms(self._handles[0], self._handles[1], ctypes.byref(ms)), "aqua_event_elapsed_ms")
+        return float(ms.value)
+
+    def close(self):
+        for e in self._handles:
+            _capi.lib.aqua_event_destroy(e)
+        self._handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PreparedRollout(object):
+    """rollout(steps, ...) with its arguments checked and marshalled once (BatchedAqua.prepare_rollout): launch() is one C
+    call -- what a captured graph is for replays, for launches that cannot be captured (events attached to them)."""
+
+    def __init__(self, env, steps, args, tick_index, reward, term, keep):
+        self._env, self.steps, self._args, self._tick_index = env, steps, list(args), tick_index
+        self.reward, self.term = reward, term
+        self._keep = keep                  # the tensors and events the marshalled pointers refer to
+
+    def launch(self):
+        env = self._env
+        self._args[self._tick_index] = env._tick
+        _capi.check(_capi.lib.aqua_rollout_events_f32(*self._args), "aqua_rollout_events_f32")
+        env._tick += self.steps
+        return self.reward, self.term
+
+
 class RolloutGraph(object):
     """A captured HIP graph of T batched steps (+ the device tick bump); replay with launch()."""
 
@@ -346,8 +402,10 @@ class BatchedAqua(object):
             raise ValueError("done_history must be int64 [T][>= ld/64]")
         return done_history, done_history.stride(0)
 
-    def rollout(self, steps, actions=None, fused=False, keep_all=True, done_history=None):
+    def rollout(self, steps, actions=None, fused=False, keep_all=True, done_history=None, events=None):
         """`steps` consecutive batched steps queued from C without returning to Python.
+        events: a LaunchEvents (or a (start, stop) pair of which either may be None) stamped by the first launch's start and
+                the last launch's end (one launch per step, one obstacle table for the batch only).
         actions: None / 'random' -> uniform random actions sampled on the device; 'bearing' -> the bearing policy
                  of main/testing/test_optimal.py evaluated on the device;
                  discrete: uint8/int32/int64 [T][>=N]; continuous: float32 [T][2][>=N].
@@ -361,6 +419,8 @@ class BatchedAqua(object):
         if fused and self.per_world and self.K > 16:
             raise NotImplementedError("the fused per-world rollout keeps tables of at most 16 rows in LDS: longer ones run as "
                                       "one launch per step (rollout(fused=False) / capture_rollout())")
+        if events is not None and (fused or self.per_world):
+            raise ValueError("rollout(events=...) times one launch per step on a batch with one obstacle table")
         with torch.cuda.device(self.device):
             if self.per_world and fused:
                 _capi.check(self._rollout_tables_fused(steps, aptr, kind, ald, astride, self._tick, None, reward, term, ostride,
@@ -375,14 +435,33 @@ class BatchedAqua(object):
                                                        self._tick, None, reward.data_ptr(), term.data_ptr(), ostride,
                                                        int(self.auto_reset), self._stream()), "aqua_rollout_fused_f32")
             else:
-                _capi.check(lib.aqua_rollout_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
-                                                 self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
-                                                 steps, aptr, kind, ald, astride, self.seed, self._tick, None,
-                                                 reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(),
-                                                 dstride, self._norm_ptr(), int(self.auto_reset), 0, self._stream()),
-                            "aqua_rollout_f32")
+                ev0, ev1 = (events.start, events.stop) if isinstance(events, LaunchEvents) else (events or (None, None))
+                _capi.check(lib.aqua_rollout_events_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs,
+                                                        self.env_offset, self.state.data_ptr(), self.ld, self.time.data_ptr(),
+                                                        steps, aptr, kind, ald, astride, self.seed, self._tick, None,
+                                                        reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(),
+                                                        dstride, self._norm_ptr(), int(self.auto_reset), 0, ev0, ev1,
+                                                        self._stream()),
+                            "aqua_rollout_events_f32")
         self._tick += steps
         return reward, term
+
+    def prepare_rollout(self, steps, actions=None, keep_all=False, done_history=None, events=None):
+        """rollout(steps, actions, keep_all=keep_all, done_history=done_history, events=events) as an object whose launch()
+        is a single C call (one launch per step, one obstacle table for the batch; queued on the stream current NOW)."""
+        if self.per_world:
+            raise ValueError("prepare_rollout(): batches with one obstacle table")
+        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld)
+        reward, term, ostride = self._rollout_out(steps, keep_all)
+        done, dstride = self._done_out(steps, done_history)
+        ev0, ev1 = (events.start, events.stop) if isinstance(events, LaunchEvents) else (events or (None, None))
+        with self.torch.cuda.device(self.device):
+            stream = self._stream()
+        args = [ctypes.byref(self.params), self._blob_ptr(), self.K, self.num_envs, self.env_offset, self.state.data_ptr(),
+                self.ld, self.time.data_ptr(), steps, aptr, kind, ald, astride, self.seed, self._tick, None,
+                reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(), dstride, self._norm_ptr(),
+                int(self.auto_reset), 0, ev0, ev1, stream]
+        return PreparedRollout(self, steps, args, 14, reward, term, (actions, done, events, reward, term))
 
     def _rollout_tables(self, steps, aptr, kind, ald, astride, tick, tick_base, reward, term, ostride, done, dstride, advance, s):
         return _capi.lib.aqua_rollout_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),

@@ -23,6 +23,7 @@
 // tools/sweep_n.sh).  The tuning constants below (tile sizes, group sizes, cache scopes) are plain constants: every
 // alternative that was measured is recorded with its timing in DESIGN.md section 5.3.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -276,7 +277,22 @@ __device__ unsigned long long* g_stamps = nullptr;
             g_stamps[(static_cast<size_t>(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (slot)] = t_; \
     } while (0)
 // AQUA_STAMPS == 2: only the wavefront-start (3) and wavefront-end (2) wall-clock stamps, to perturb less
-#if AQUA_STAMPS == 2
+// AQUA_STAMPS == 3: those two, kept per launch for the last 32 launches (tools/r03/burst_timeline.py)
+#if AQUA_STAMPS == 3
+__device__ __forceinline__ uint64_t launch_tick(const StepArgs& a);
+#define AQUA_STAMP(slot) do { } while (0)
+#define AQUA_RTSTAMP(slot)                                                                            \
+    do {                                                                                              \
+        if ((slot) == 2 || (slot) == 3) {                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                      \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            if (g_stamps != nullptr && (threadIdx.x & 63) == 0)                                       \
+                g_stamps[(((launch_tick(a) & 31u) * gridDim.x + blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64) * 2 + ((slot) == 2)] = t_; \
+        }                                                                                             \
+    } while (0)
+#elif AQUA_STAMPS == 2
 #define AQUA_STAMP(slot) do { } while (0)
 #define AQUA_RTSTAMP(slot) do { if ((slot) == 2 || (slot) == 3) AQUA_STAMP_IMPL(slot, "s_memrealtime"); } while (0)
 #else
@@ -1828,7 +1844,21 @@ size_t action_elem_bytes(int kind)
     }
 }
 
-hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
+// Events attached to a LAUNCH (aqua_rollout_events_f32): `start` takes the kernel's own start time, `stop` its end time --
+// no marker packet of their own in the queue (a recorded stream event is one, and a pair of them around a region costs
+// the region 12-14 us: profiles/r03/burst_timeline.txt).
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+template <typename Kernel, typename... Args>
+void launch_kernel(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, const LaunchEvents& ev, Args... args)
+{
+    if (ev.start == nullptr && ev.stop == nullptr) hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+    else hipExtLaunchKernelGGL(kernel, grid, block, 0, s, ev.start, ev.stop, 0, args...);
+}
+
+hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s, const LaunchEvents& ev = {})
 {
     if ((a.N + TILE_WORLDS - 1) / TILE_WORLDS > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(grid_for(a.N, TILE_WORLDS, MAX_GRID)), block(TILE_WORLDS);
@@ -1837,12 +1867,12 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     const bool wb = !plain && a.N >= STORE_WB_SAME_STEP_MIN;
 #define AQUA_STEP_LAUNCH(AK)                                                                                     \
     case AK:                                                                                                     \
-        if (plain && small) hipLaunchKernelGGL((step_kernel<AK, true, false>), grid, block, 0, s, a);            \
-        else if (plain) hipLaunchKernelGGL((step_kernel<AK, false, false>), grid, block, 0, s, a);               \
-        else if (small && wb) hipLaunchKernelGGL((step_kernel<AK, true, true, true>), grid, block, 0, s, a);     \
-        else if (wb) hipLaunchKernelGGL((step_kernel<AK, false, true, true>), grid, block, 0, s, a);             \
-        else if (small) hipLaunchKernelGGL((step_kernel<AK, true, true>), grid, block, 0, s, a);                 \
-        else hipLaunchKernelGGL((step_kernel<AK, false, true>), grid, block, 0, s, a);                           \
+        if (plain && small) launch_kernel((step_kernel<AK, true, false>), grid, block, s, ev, a);            \
+        else if (plain) launch_kernel((step_kernel<AK, false, false>), grid, block, s, ev, a);               \
+        else if (small && wb) launch_kernel((step_kernel<AK, true, true, true>), grid, block, s, ev, a);     \
+        else if (wb) launch_kernel((step_kernel<AK, false, true, true>), grid, block, s, ev, a);             \
+        else if (small) launch_kernel((step_kernel<AK, true, true>), grid, block, s, ev, a);                 \
+        else launch_kernel((step_kernel<AK, false, true>), grid, block, s, ev, a);                           \
         break;
     switch (kind) {
         AQUA_STEP_LAUNCH(AQUA_ACT_U8)
@@ -1858,7 +1888,7 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
+hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s, const LaunchEvents& ev = {})
 {
     StepArgs a = a0;
     a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
@@ -1871,12 +1901,12 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     const bool small = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;
 #define AQUA_NS_LAUNCH(AK)                                                                           \
     case AK:                                                                                         \
-        if (small && wb) hipLaunchKernelGGL((step_ns_kernel<AK, true, true, true>), grid, block, 0, s, a);          \
-        else if (wb) hipLaunchKernelGGL((step_ns_kernel<AK, false, true, true>), grid, block, 0, s, a);             \
-        else if (small && interleave) hipLaunchKernelGGL((step_ns_kernel<AK, true, true>), grid, block, 0, s, a);   \
-        else if (small) hipLaunchKernelGGL((step_ns_kernel<AK, true, false>), grid, block, 0, s, a);                \
-        else if (interleave) hipLaunchKernelGGL((step_ns_kernel<AK, false, true>), grid, block, 0, s, a);           \
-        else hipLaunchKernelGGL((step_ns_kernel<AK, false, false>), grid, block, 0, s, a);                          \
+        if (small && wb) launch_kernel((step_ns_kernel<AK, true, true, true>), grid, block, s, ev, a);          \
+        else if (wb) launch_kernel((step_ns_kernel<AK, false, true, true>), grid, block, s, ev, a);             \
+        else if (small && interleave) launch_kernel((step_ns_kernel<AK, true, true>), grid, block, s, ev, a);   \
+        else if (small) launch_kernel((step_ns_kernel<AK, true, false>), grid, block, s, ev, a);                \
+        else if (interleave) launch_kernel((step_ns_kernel<AK, false, true>), grid, block, s, ev, a);           \
+        else launch_kernel((step_ns_kernel<AK, false, false>), grid, block, s, ev, a);                          \
         break;
     switch (kind) {
         AQUA_NS_LAUNCH(AQUA_ACT_U8)
@@ -1892,10 +1922,10 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_step_any(const StepArgs& a, int kind, hipStream_t s)
+hipError_t launch_step_any(const StepArgs& a, int kind, hipStream_t s, const LaunchEvents& ev = {})
 {
-    if (a.auto_reset == AQUA_RESET_NEXT_STEP) return launch_step_ns(a, kind, s);
-    return launch_step(a, kind, s);
+    if (a.auto_reset == AQUA_RESET_NEXT_STEP) return launch_step_ns(a, kind, s, ev);
+    return launch_step(a, kind, s, ev);
 }
 
 int check_step_buffers(int64_t N, const void* action, int action_kind, int64_t action_ld, const float* noise,
@@ -2067,6 +2097,18 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
                      uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, int advance_tick,
                      void* stream)
 {
+    return aqua_rollout_events_f32(p, obst_blob_dev, K, N, env_offset, state, ld, time, T, actions, action_kind, action_ld,
+                                   action_step_stride, seed, tick, tick_base_dev, reward, term, out_step_stride, done_bits,
+                                   done_step_stride, obs_norm, auto_reset, advance_tick, nullptr, nullptr, stream);
+}
+
+int aqua_rollout_events_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
+                            float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
+                            int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
+                            const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
+                            uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, int advance_tick,
+                            AquaEvent* first_start, AquaEvent* last_stop, void* stream)
+{
     StepArgs a;
     int rc = fill_args(a, p, obst_blob_dev, K, N, env_offset, state, ld, time, seed, tick, tick_base_dev);
     if (rc) return rc;
@@ -2092,7 +2134,10 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
         a.reward = reward + t * out_step_stride;
         a.term = term + t * out_step_stride;
         a.done_bits = done_bits ? done_bits + t * done_step_stride : nullptr;
-        const hipError_t e = launch_step_any(a, action_kind, static_cast<hipStream_t>(stream));
+        LaunchEvents ev;
+        if (t == 0 && first_start != nullptr) ev.start = first_start->event;
+        if (t == T - 1 && last_stop != nullptr) ev.stop = last_stop->event;
+        const hipError_t e = launch_step_any(a, action_kind, static_cast<hipStream_t>(stream), ev);
         if (e != hipSuccess) return hip_fail(e, "aqua_rollout_f32 launch");
     }
     if (advance_tick && T == 1) return aqua_tick_advance(tick_words, 1, stream);   // one launch cannot do both halves

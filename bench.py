@@ -77,6 +77,15 @@ def parse(argv=None):
     ap.add_argument("--graph-node-events", action="store_true",
                     help="diagnostic: a region that is one graph ALSO carries event-record nodes at its head and tail "
                          "(round 2's clock), reported beside the stream events as roofline.launch_us_graph_nodes_regions")
+    ap.add_argument("--region-clock", choices=("stream", "launch"), default="stream",
+                    help="the roofline's clock.  stream (default): HIP events recorded on the launch stream around the region's "
+                         "graph launches -- two marker packets, 12-14 us per region beyond first kernel start -> last kernel end "
+                         "(profiles/r03/burst_timeline.txt).  launch (diagnostic, regions of one block of <= %d steps): the region "
+                         "is queued by one C call of plain launches, its events ATTACHED to the first launch (start time) and the "
+                         "last one (end time) by hipExtLaunchKernel; the stream events are recorded as well and reported beside "
+                         "them.  Measured on one box at --steps 20 (profiles/r03/region_clock.txt): 5.1-5.4 us per step by the "
+                         "attached events against 5.5 by the stream events around a graph -- and 13-17 %% less throughput by wall "
+                         "clock, noisier regions (the host queues every launch): not the default" % CHUNK)
     ap.add_argument("--settle-us", type=float, default=0.0,
                     help="diagnostic: host pause between the barrier that closes a region and the start of the next region's "
                          "clock (outside every timed interval).  A 20-step graph launched 200 us after a device "
@@ -123,9 +132,10 @@ class StepRunner(object):
     (prepare()).  With an `exchange` (DoneMaskExchange) each completed block is all-gathered on the side
     stream; the step stream only waits for the gather that last read the buffer it is about to overwrite."""
 
-    def __init__(self, env, actions, hist, exchange=None, use_graph=True, chunk=CHUNK):
+    def __init__(self, env, actions, hist, exchange=None, use_graph=True, chunk=CHUNK, launch_events=None):
         self.env, self.actions, self.hist, self.exchange = env, actions, hist, exchange
         self.use_graph, self.chunk = use_graph, chunk
+        self.launch_events = launch_events               # a LaunchEvents: one-block regions of run(clock=True) carry it
         self.block_rows = int(hist[0].shape[0])
         self.graphs = {}
         self._plans = {}
@@ -179,18 +189,37 @@ class StepRunner(object):
             self.timing_error = "%s: %s" % (type(exc).__name__, exc)
             return None
 
-    def run(self, n_steps, after_last_launch=None, before_first_launch=None):
+    def clocked_by_launch_events(self, n_steps):
+        """a region of one block can carry events attached to its first and last launch: it is then queued by ONE C call of
+        plain launches (hipExtLaunchKernel for those two) instead of a graph, whose nodes cannot carry events.  (The first
+        and the last step as launches of their own around the graph of the others was measured too: 5.29 us per step where
+        the one call gives 5.14 and graph + stream events 5.46 -- every change of submission path costs.)"""
+        return self.launch_events is not None and len(self.plan(n_steps)) == 1
+
+    def prepare_clocked(self, n_steps):
+        """a one-block region that carries the launch events: its launches marshalled once (what capture is for a graph)"""
+        (buf, row0, s, _), = self.plan(n_steps)
+        key = ("clocked", buf, row0, s)
+        if key not in self.graphs:
+            self.graphs[key] = self.env.prepare_rollout(s, actions=self.actions, keep_all=False,
+                                                        done_history=self.hist[buf][row0:row0 + s], events=self.launch_events)
+
+    def run(self, n_steps, after_last_launch=None, before_first_launch=None, clock=False):
         """exactly n_steps steps; returns the segments it queued.  before_first_launch() is called right ahead of the
         region's first step launch, after_last_launch() right behind its last one and ahead of the exchange of its last
         block: where bench.py records its HIP events, so that the exchange's host-side bookkeeping (on an idle stream an
-        event is stamped at once) is not inside the interval"""
+        event is stamped at once) is not inside the interval.  clock=True: a one-block region is queued by rollout() with
+        self.launch_events attached to its first and last launch"""
         segs = self.plan(n_steps)
+        by_launch = clock and self.clocked_by_launch_events(n_steps)
         for i, (buf, row0, s, gather_after) in enumerate(segs):
             if self.exchange is not None and row0 == 0:
                 self.exchange.wait_source(buf)
             if before_first_launch is not None and i == 0:
                 before_first_launch()
-            if self.use_graph:
+            if by_launch:
+                self.graphs[("clocked", buf, row0, s)].launch()
+            elif self.use_graph:
                 self.graphs[(buf, row0, s)].launch()
             else:
                 self.env.rollout(s, actions=self.actions, keep_all=False, done_history=self.hist[buf][row0:row0 + s])
@@ -432,7 +461,7 @@ def main(argv=None):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from aquaticgymenv_amd.batched import BatchedAqua
+    from aquaticgymenv_amd.batched import BatchedAqua, LaunchEvents
     from aquaticgymenv_amd.sharded import DoneMaskExchange
 
     one_gpu = args.ranks_on_one_gpu
@@ -474,9 +503,16 @@ def main(argv=None):
         slots = max(exchange_blocks(args.warmup, chunk, block_rows), exchange_blocks(args.steps, chunk, block_rows), 1)
         exchange, exchange_kind, exchange_note = make_exchange("ipc" if one_gpu else args.exchange, block_rows, words, dev, slots,
                                                                rank, ranks_seen, torch, DoneMaskExchange, args.copy_engine)
-    runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk)
+    runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk,
+                        launch_events=LaunchEvents() if args.region_clock == "launch" else None)
+    by_launch = runner.clocked_by_launch_events(args.steps)
+    if args.region_clock == "launch" and not by_launch:
+        raise SystemExit("--region-clock launch: a region of %d steps is more than one block of %d" % (args.steps, chunk))
     runner.prepare(args.warmup)
-    runner.prepare(args.steps, timing=args.graph_node_events)
+    if by_launch:
+        runner.prepare_clocked(args.steps)
+    else:
+        runner.prepare(args.steps, timing=args.graph_node_events)
 
     def drain():
         """everything this rank queued has run: the steps, and the done-mask gathers behind them on the side stream"""
@@ -499,7 +535,7 @@ def main(argv=None):
     drain()
     rendezvous()
     x_before = float(env.state[0, :n].double().sum().item())
-    walls, events, node_ms, segs = [], [], [], []
+    walls, events, launch_ev, node_ms, segs = [], [], [], [], []
     for _ in range(args.regions):
         # HIP events on the stream the step kernels are launched on, around the region's launches (the contract's
         # `roofline` clock).  Round 2 timed a one-graph region with event-record NODES inside the graph instead: measured
@@ -509,12 +545,13 @@ def main(argv=None):
             time.sleep(args.settle_us * 1e-6)
         t0 = time.perf_counter()
         segs = runner.run(args.steps, before_first_launch=lambda: e0.record(launch_stream),
-                          after_last_launch=lambda: e1.record(launch_stream))
+                          after_last_launch=lambda: e1.record(launch_stream), clock=True)
         drain()
         walls.append(time.perf_counter() - t0)
         rendezvous()
         events.append(e0.elapsed_time(e1))               # ms
-        node_ms.append(runner.region_graph_ms(segs) if args.graph_node_events else None)
+        launch_ev.append(runner.launch_events.elapsed_ms() if by_launch else None)
+        node_ms.append(runner.region_graph_ms(segs) if args.graph_node_events and not by_launch else None)
     if distributed:
         tmax = torch.tensor(walls, dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -551,7 +588,9 @@ def main(argv=None):
         # the step kernel is the only kernel in the timed stream: its average launch period on the launch stream
         # (HIP events around the region: inter-kernel boundaries and the event-to-first-kernel gap included, so
         # this is an upper bound of the kernel's own duration); median over the regions
-        launch_s = statistics.median(events) * 1e-3 / args.steps
+        # (a one-block region carries its events ON its first and last launch instead: the two stream events are marker
+        # packets of their own and read 12-14 us more per region than first kernel start -> last kernel end)
+        launch_s = statistics.median(launch_ev if by_launch else events) * 1e-3 / args.steps
         achieved = a_bytes * n / launch_s / 1e9
         traffic, traffic_src = committed_traffic(n, args)
         result = {
@@ -564,10 +603,11 @@ def main(argv=None):
                        % (n, "continuous f32x2" if args.continuous else "discrete u8",
                           "no obstacles" if args.no_obstacles else "4 circle + 4 rect obstacles",
                           "off" if args.no_auto_reset else ("next-step" if args.reset_mode == 2 else "same-step"),
-                          "HIP graphs" if runner.use_graph else "eager launch loops", chunk),
+                          "one C call of launches per region" if by_launch else
+                          ("HIP graphs" if runner.use_graph else "eager launch loops"), chunk),
                        "baseline_config": "configs[3]" if args.continuous else ("configs[1]-like" if args.no_obstacles else "configs[2]"),
                        "worlds_per_gpu": n, "global_worlds": world * n, "parallelism": "range-partition x%d" % world,
-                       "launch": runner.launch, "done_mask_exchange": exchange is not None,
+                       "launch": "eager" if by_launch else runner.launch, "done_mask_exchange": exchange is not None,
                        "done_mask_exchange_kind": exchange_kind, "done_mask_exchange_note": exchange_note,
                        "done_mask_copy_engine": args.copy_engine if exchange_kind == "ipc" else None,
                        "ranks_seen": ranks_seen, "devices": devices,
@@ -577,13 +617,22 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
-                         "launch_us_regions": [e * 1e3 / args.steps for e in events],
-                         "launch_us_events": "stream",
+                         "launch_us_regions": [e * 1e3 / args.steps for e in (launch_ev if by_launch else events)],
+                         "launch_us_events": "launch" if by_launch else "stream",
+                         "launch_us_stream_events_regions": [e * 1e3 / args.steps for e in events],
+                         "frac_by_stream_events": a_bytes * n / (statistics.median(events) * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBPS,
                          "launch_us_graph_nodes_regions": ([g * 1e3 / args.steps if g else None for g in node_ms]
                                                            if args.graph_node_events else None),
-                         "note": "launch_us = HIP-event time of a timed region / its launches, median region, inter-kernel "
-                                 "boundaries included; the events are recorded on the launch stream around the region's "
-                                 "graph launches.  Kernel-only duration: profiles/"},
+                         "note": ("launch_us = HIP-event time of a timed region / its launches, median region, inter-kernel "
+                                  "boundaries included.  The two events are ATTACHED to the region's first launch (its start time) "
+                                  "and last launch (its end time) -- hipExtLaunchKernel's start/stop events, on the launch stream; the "
+                                  "region is one C call of plain launches (a graph node cannot carry events); "
+                                  "launch_us_stream_events_regions / frac_by_stream_events: the same regions by two events RECORDED "
+                                  "on that stream around them (rounds 1-2's clock: two marker packets, 12-14 us per region more, "
+                                  "profiles/r03/burst_timeline.txt).  Kernel-only duration: profiles/" if by_launch else
+                                  "launch_us = HIP-event time of a timed region / its launches, median region, inter-kernel "
+                                  "boundaries included; the events are recorded on the launch stream around the region's "
+                                  "graph launches.  Kernel-only duration: profiles/")},
             "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended,
                        "done_mask_exchange_last_block": exchange_check},
         }

@@ -35,10 +35,11 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 5   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
+#define AQUA_ABI_VERSION 6   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
                                 3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed;
                                 4: aqua_rollout_tables_fused_f32;
-                                5: aqua_ipc_*, aqua_copy_async (done-mask exchange by peer copies) */
+                                5: aqua_ipc_*, aqua_copy_async (done-mask exchange by peer copies);
+                                6: aqua_rollout_events_f32 (events attached to the first / last launch) */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
@@ -155,6 +156,23 @@ int aqua_rollout_f32(const AquaParams* p, const void* obst_blob_dev, int K, int6
                      void* stream);
 
 /*
+ * aqua_rollout_f32 with a clock on it: `first_start` (nullable) receives the START time of the first step launch,
+ * `last_stop` (nullable) the END time of the last one (hipExtLaunchKernel's start / stop events: the timestamps of the
+ * kernels' own dispatch packets).  aqua_event_elapsed_ms(first_start, last_stop) is then the time from the first
+ * wavefront's start to the last kernel's end -- launches and the boundaries between them, nothing else.  Events RECORDED
+ * on the stream around the same launches (aqua_event_record) are marker packets of their own and read 12-14 us more per
+ * pair (profiles/r03/burst_timeline.txt).  Not capturable into a graph (a graph node carries no events); with N == 0 or
+ * T == 0 the events are left untouched.  Both events must be complete before they are read (synchronise the stream).
+ */
+typedef struct AquaEvent AquaEvent;
+int aqua_rollout_events_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
+                            float* state, int64_t ld, int32_t* time, int64_t T, const void* actions, int action_kind,
+                            int64_t action_ld, int64_t action_step_stride, uint64_t seed, uint64_t tick,
+                            const uint64_t* tick_base_dev, float* reward, uint8_t* term, int64_t out_step_stride,
+                            uint64_t* done_bits, int64_t done_step_stride, float* obs_norm, int auto_reset, int advance_tick,
+                            AquaEvent* first_start, AquaEvent* last_stop, void* stream);
+
+/*
  * The same T steps fused into ONE launch: pose, goal, wave and time stay in registers between
  * steps, so HBM traffic per world-step drops to the action read and the reward/term writes.
  * Results are identical to aqua_rollout_f32 with the same arguments (tests/test_hip_parity.py).
@@ -245,7 +263,7 @@ int aqua_graph_destroy(AquaGraph* g);
  * captured launches (bench.py's roofline.launch_us: no host launch latency inside the interval).
  * aqua_event_elapsed_ms() needs both events recorded and complete (synchronise the stream first).
  */
-typedef struct AquaEvent AquaEvent;
+/* (AquaEvent is declared above, with aqua_rollout_events_f32) */
 int aqua_event_create(AquaEvent** out);
 int aqua_event_record(AquaEvent* e, void* stream);
 int aqua_graph_end_timed(void* stream, AquaGraph** out, AquaEvent* start, AquaEvent* stop);

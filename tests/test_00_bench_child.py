@@ -31,21 +31,29 @@ def _run(cmd, timeout=900):
     return json.loads(lines[0])
 
 
-def _check_line(r, steps, warmup, n_gpus=1, envs=262144, timings_mean_something=True):
+def _check_line(r, steps, warmup, n_gpus=1, envs=262144, timings_mean_something=True, clock=None):
+    clock = clock or "stream"                                      # bench.py's default --region-clock
     assert r["steps"] == steps and r["warmup"] == warmup and r["n_gpus"] == n_gpus
     assert r["unit"] == "env-steps/s" and r["higher_is_better"] is True and r["scaling"] == "weak"
     assert r["value"] > (1.0e7 if timings_mean_something else 0.0), "below the 10 M env-steps/s target: %r" % r["value"]
     assert abs(r["value"] - n_gpus * envs * steps / (r["ms_per_step"] * 1e-3 * steps)) <= 1e-6 * r["value"]
     assert r["config"]["baseline_config"] == "configs[2]" and str(envs) in r["config"]["workload"]
     assert r["config"]["ranks_seen"] == n_gpus and len(r["config"]["devices"]) == n_gpus
-    assert r["config"]["launch"] == "hipGraph"
+    assert r["config"]["launch"] == ("eager" if clock == "launch" else "hipGraph")
     assert len(r["regions_ms"]) == r["regions"] == 5
     assert sorted(r["regions_ms"])[2] == pytest.approx(r["ms_per_step"] * steps)
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"])
     assert roof["achieved"] == pytest.approx(62 * envs / (roof["launch_us"] * 1e-6) / 1e9)
-    assert roof["launch_us_events"] == "stream" and len(roof["launch_us_regions"]) == 5
+    assert roof["launch_us_events"] == clock and len(roof["launch_us_regions"]) == 5
+    assert len(roof["launch_us_stream_events_regions"]) == 5 and 0.0 < roof["frac_by_stream_events"] < 1.0
+    if clock == "launch" and timings_mean_something:
+        # first kernel start -> last kernel end lies INSIDE the two stream events recorded around the same launches
+        assert all(a <= b * 1.001 for a, b in zip(roof["launch_us_regions"], roof["launch_us_stream_events_regions"]))
+        assert roof["frac_by_stream_events"] <= roof["frac"] * 1.001
+    elif clock == "stream":
+        assert roof["launch_us_regions"] == roof["launch_us_stream_events_regions"]
     assert (0.05 if timings_mean_something else 0.0) < roof["frac"] < 1.0
     assert "traffic" in roof and "traffic_source" in roof
     assert r["sanity"]["steps_queued"] == warmup + 5 * steps
@@ -83,6 +91,8 @@ def test_bench_diagnostic_flags_in_a_child_process():
     assert len(nodes) == 5 and all(v and v > 1.0 for v in nodes)
     assert r["config"]["done_mask_exchange_kind"] == "ipc" and r["config"]["done_mask_copy_engine"] == "dma"
     assert r["sanity"]["done_mask_exchange_last_block"]["own_block_intact"] is True
+    r = _run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--region-clock", "launch"])
+    _check_line(r, 20, 5, clock="launch")               # the events attached to the region's first and last launch
     r = _run([sys.executable, "bench.py", "--steps", "30", "--warmup", "3", "--no-cpu-baseline", "--eager"])
     assert r["config"]["launch"] == "eager" and r["steps"] == 30 and r["sanity"]["steps_queued"] == 3 + 5 * 30
 

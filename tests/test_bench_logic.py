@@ -9,11 +9,11 @@ import bench
 
 
 class StubGraph(object):
-    def __init__(self, env, steps, done_history):
-        self.env, self.steps, self.done_history = env, steps, done_history
+    def __init__(self, env, steps, done_history, how="graph"):
+        self.env, self.steps, self.done_history, self.how = env, steps, done_history, how
 
     def launch(self):
-        self.env._do(self.steps, self.done_history, "graph")
+        self.env._do(self.steps, self.done_history, self.how)
 
 
 class StubEnv(object):
@@ -36,8 +36,13 @@ class StubEnv(object):
         self.captured.append(steps)
         return StubGraph(self, steps, done_history)
 
-    def rollout(self, steps, actions=None, keep_all=False, done_history=None):
-        self._do(steps, done_history, "eager")
+    def rollout(self, steps, actions=None, keep_all=False, done_history=None, events=None):
+        self._do(steps, done_history, "eager" if events is None else "eager+events")
+
+    def prepare_rollout(self, steps, actions=None, keep_all=False, done_history=None, events=None):
+        assert events is not None
+        self.prepared = getattr(self, "prepared", []) + [steps]
+        return StubGraph(self, steps, done_history, how="prepared+events")
 
 
 class StubExchange(object):
@@ -106,6 +111,28 @@ def test_runner_queues_exactly_the_requested_steps(steps, warmup, use_graph):
     assert r.launch == ("hipGraph" if use_graph else "eager")
     if use_graph:
         assert max(env.captured) <= chunk
+
+
+def test_one_block_regions_carry_the_launch_events():
+    """run(clock=True): a region of one block is queued by ONE prepared call of plain launches with the events attached to
+    its first and last launch (no graph); longer regions, and regions run without the clock, stay on their graphs"""
+    env, hist = StubEnv(), _hist()
+    r = bench.StepRunner(env, None, hist, None, use_graph=True, chunk=bench.CHUNK, launch_events=object())
+    assert r.clocked_by_launch_events(20) and r.clocked_by_launch_events(bench.CHUNK)
+    assert not r.clocked_by_launch_events(bench.CHUNK + 1) and not r.clocked_by_launch_events(2000)
+    r.prepare(5)
+    r.prepare_clocked(20)
+    assert env.captured == [5] and env.prepared == [20]
+    r.run(5)                                  # warm-up: a graph, as before
+    order = []
+    r.run(20, before_first_launch=lambda: order.append("e0"), after_last_launch=lambda: order.append("e1"), clock=True)
+    assert env.calls == [("graph", 5), ("prepared+events", 20)] and order == ["e0", "e1"] and env._tick == 25
+    assert (hist[0][:20, 0] == np.arange(6, 26)).all()          # every step wrote its own done-mask row, in order
+    r.prepare(250)
+    r.run(250, clock=True)                    # three blocks: graphs, the stream events are the clock
+    assert [how for how, _ in env.calls[2:]] == ["graph"] * 3
+    plain = bench.StepRunner(StubEnv(), None, _hist(), None, use_graph=True, chunk=bench.CHUNK)
+    assert not plain.clocked_by_launch_events(20)          # --region-clock stream
 
 
 def test_runner_exchange_handoffs():

@@ -15,7 +15,10 @@ lib.aqua_graph_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
 lib.aqua_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 buf = torch.zeros(11 * n, dtype=torch.float32, device="cuda")
 stream = torch.cuda.Stream()
-for kind, block, spin in ((0, 512, 0), (0, 256, 0), (1, 512, 0), (1, 256, 0), (2, 512, 1)):
+# kinds 3-7 (round 3): the state as 32-byte records (3, 5: a record per lane; 6, 7: consecutive 16-byte pieces per lane and an
+# LDS transposition), and the layouts with ~2 % of the worlds restarting (4, 5, 7)
+for kind, block, spin in ((0, 512, 0), (0, 256, 0), (1, 512, 0), (1, 256, 0), (2, 512, 1), (3, 256, 0), (4, 256, 0), (5, 256, 0),
+                          (6, 256, 0), (7, 256, 0), (1, 256, 0), (4, 256, 0), (6, 256, 0), (7, 256, 0)):
     with torch.cuda.stream(stream):
         s = stream.cuda_stream
         _capi.check(lib.aqua_graph_begin(s), "begin")
