@@ -416,9 +416,6 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
-        if fused and self.per_world and self.K > 16:
-            raise NotImplementedError("the fused per-world rollout keeps tables of at most 16 rows in LDS: longer ones run as "
-                                      "one launch per step (rollout(fused=False) / capture_rollout())")
         if events is not None and (fused or self.per_world):
             raise ValueError("rollout(events=...) times one launch per step on a batch with one obstacle table")
         with torch.cuda.device(self.device):
@@ -487,9 +484,6 @@ class BatchedAqua(object):
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
-        if fused and self.per_world and self.K > 16:
-            raise NotImplementedError("the fused per-world rollout keeps tables of at most 16 rows in LDS: longer ones are "
-                                      "captured as one launch per step (fused=False)")
         self._sync_device_tick()
         cap = torch.cuda.Stream(device=self.device)
         cap.wait_stream(torch.cuda.current_stream(self.device))

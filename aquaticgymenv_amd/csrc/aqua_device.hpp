@@ -780,12 +780,11 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // ROWS == RESEED_HANDOFF8: per-world tables of at most eight rows whose rows the world's OWN lane already holds in
 // registers: it has left them in LDS (`rows` is the group's slot, a per-lane LDS pointer; rows past the table's end
 // repeat its last row) -- no memory round trip at all.  The rare serial scan falls back to the table in memory (`wt`).
-// ROWS == RESEED_SOA8 / RESEED_SOA16: the same, for a block that keeps the tables of ALL its worlds in LDS as
-// [row][field][lane] (the fused per-world rollout, tables of up to 8 / 16 rows): `rows` points at the world's column,
-// fields RESEED_SOA_STRIDE floats apart.
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA8 = -5, RESEED_SOA16 = -6;
-constexpr int RESEED_SOA_STRIDE = 256;
-template <int G, int ROWS = 0>
+// ROWS == RESEED_SOA: the same, for a block that keeps the tables of ALL its worlds in LDS as [row][field][world] (the
+// fused per-world rollout: SOA_ROWS = 8 / 16 / 32 / 64 rows, SOA_STRIDE = 256 / 256 / 128 / 64 worlds per block): `rows`
+// points at the world's column, fields SOA_STRIDE floats apart.
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5;
+template <int G, int ROWS = 0, int SOA_ROWS = 8, int SOA_STRIDE = 256>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
                                                      const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
@@ -848,20 +847,24 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
             }
-        } else if constexpr (ROWS == RESEED_SOA8 || ROWS == RESEED_SOA16) {
+        } else if constexpr (ROWS == RESEED_SOA) {
+            // rows in flight at a time: two (as above) for short tables; eight for the long ones, whose pass is otherwise
+            // 32 LDS round trips one behind the other (the block has registers to spare: it is alone on its CU)
+            constexpr int RS = SOA_ROWS >= 32 ? 8 : 2;
+            static_assert(SOA_ROWS % RS == 0, "whole batches of rows");
             const float* const soa = reinterpret_cast<const float*>(rows);
 #pragma unroll
-            for (int h = 0; h < (ROWS == RESEED_SOA16 ? 16 : 8); h += 2) {
+            for (int h = 0; h < SOA_ROWS; h += RS) {
                 int first_row = h;
                 asm volatile("" : "+v"(first_row));      // (as above: the reads stay next to their use)
-                const float* r = soa + first_row * 5 * RESEED_SOA_STRIDE;
-                float c[2][5];
+                const float* r = soa + first_row * 5 * SOA_STRIDE;
+                float c[RS][5];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < RS; ++j)
 #pragma unroll
-                    for (int f = 0; f < 5; ++f) c[j][f] = r[(j * 5 + f) * RESEED_SOA_STRIDE];
+                    for (int f = 0; f < 5; ++f) c[j][f] = r[(j * 5 + f) * SOA_STRIDE];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
+                for (int j = 0; j < RS; ++j) test(c[j][0], c[j][1], c[j][2], c[j][3], c[j][4]);
                 uint32_t fg = hit_g, fb = hit_b;
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
@@ -927,7 +930,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_SOA8 || ROWS == RESEED_SOA16) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_SOA) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

@@ -1458,34 +1458,43 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
 }
 
 // ------------------------------------------------------------------ per-world tables: T steps in one launch
-// rollout_kernel for batches in which every world has its own table (of at most KT = 8 or 16 rows): the state stays in
-// registers for the whole rollout and the block's tables stay in LDS -- 5 KT floats per world as [row][field][lane] (40 or
-// 80 KB per 256-world block), read conflict-free by the world's own lane in every step and, as a broadcast, by the eight
-// lanes that re-seed it.  Here the LDS tile pays (it did not for the one-launch-per-step kernel): every
-// row is used T times.  HBM traffic per world-step: the action in, reward and term out.  Restart protocol, markers and
-// results: rollout_kernel's, i.e. T launches of the per-step kernels bit for bit.  (Longer tables do not fit the LDS of a
-// CU beside a second block; they run as one launch per step.)
-static_assert(RESEED_SOA_STRIDE == BLOCK_SMALL, "one column of the LDS table tile per lane");
-constexpr int FUSED_TABLE_ROWS_MAX = 16;
-template <int KT>
+// rollout_kernel for batches in which every world has its own table (of at most KT = 8, 16, 32 or 64 rows): the state stays
+// in registers for the whole rollout and the block's tables stay in LDS -- 5 KT floats per world as [row][field][world],
+// read conflict-free by the world's own lane in every step and, as a broadcast, by the eight lanes that re-seed it.  Here
+// the LDS tile pays (it did not for the one-launch-per-step kernel): every row is used T times.  HBM traffic
+// per world-step: the action in, reward and term out.  Restart protocol, markers and results: rollout_kernel's, i.e. T
+// launches of the per-step kernels bit for bit.
+// The tile is 40 KB (KT = 8) or 80 KB per block.  Up to 16 rows a block of 256 lanes holds 256 worlds; longer tables keep
+// the 80 KB by giving the block fewer WORLDS (WPB = 128 for up to 32 rows, 64 for up to 64) -- the block stays 256 lanes,
+// the lanes without a world of their own idle through the steps and take their turn at re-seeding: the restart protocol
+// (lists, tickets, the serving wavefront rotating with the tick) is then the one of the full block, unchanged.
+constexpr int FUSED_TABLE_ROWS_MAX = 64;
+static_assert(FUSED_TABLE_ROWS_MAX == AQUA_MAX_OBSTACLES, "every table the library accepts has a fused rollout");
+template <int KT, int WPB>
 struct RolloutTablesShared {
     RolloutShared r;
-    float rows[KT * 5][BLOCK_SMALL];
+    float rows[KT * 5][WPB];
 };
 
-template <int KT>
+template <int KT, int WPB>
 __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, const StepArgs& a, uint64_t tick, int64_t block_first_world,
-                                                    RolloutTablesShared<KT>& sh, int parity, const float* __restrict__ t32_tile, int64_t tld)
+                                                    RolloutTablesShared<KT, WPB>& sh, int parity, const float* __restrict__ t32_tile, int64_t tld)
 {
     constexpr int WAVES = BLOCK_SMALL / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (tk.n == 0 || wave != static_cast<int>(tick & (WAVES - 1))) return;
+    // Who re-seeds.  A full block (256 worlds): ONE wavefront, a different one every tick, while the others go on to their
+    // step.  A block of 128 or 64 worlds has wavefronts without worlds: all of those, sharing the list -- at 64 rows per
+    // table and every sixth world restarting per step a single server was the whole step (126 us per step; the
+    // one-launch-per-step kernels 113).
+    constexpr int WORLD_WAVES = WPB / 64, SERVERS = WPB == BLOCK_SMALL ? 1 : WAVES - WORLD_WAVES;
+    const int server = WPB == BLOCK_SMALL ? (wave == static_cast<int>(tick & (WAVES - 1)) ? 0 : -1) : wave - WORLD_WAVES;
+    if (tk.n == 0 || server < 0) return;
     uint32_t first[WAVES + 1];
     first[0] = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.r.count[parity][w];
     constexpr uint32_t PER_PASS = 64 / RESET_GROUP;
-    for (uint32_t qb = 0; qb < tk.n; qb += PER_PASS) {
+    for (uint32_t qb = static_cast<uint32_t>(server) * PER_PASS; qb < tk.n; qb += SERVERS * PER_PASS) {
         const uint32_t q = qb + (lane / RESET_GROUP);
         const bool active = q < tk.n;
         uint32_t seg = 0;
@@ -1494,7 +1503,7 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
         const uint32_t owner = sh.r.list[parity][seg][active ? q - first[seg] : 0];
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
         const WorldTable own{t32_tile, nullptr, tld, owner};
-        const EnvState f = reset_env_group<RESET_GROUP, KT == 16 ? RESEED_SOA16 : RESEED_SOA8>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
+        const EnvState f = reset_env_group<RESET_GROUP, RESEED_SOA, KT, WPB>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
                                                                       nullptr, reinterpret_cast<const ObstF*>(&sh.rows[0][owner]), nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.r.result[q];
@@ -1503,32 +1512,36 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
     }
 }
 
-template <int AK, int MODE, int KT>
+template <int AK, int MODE, int KT, int WPB>
 __device__ __forceinline__ void rollout_tables_body(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
-                                                    int64_t tld, float band2, float band2_tight, RolloutTablesShared<KT>& sh)
+                                                    int64_t tld, float band2, float band2_tight, RolloutTablesShared<KT, WPB>& sh)
 {
-    static_assert(KT == 8 || KT == 16, "LDS tile of 8 or 16 rows");
+    static_assert((KT == 8 || KT == 16 || KT == 32 || KT == 64) && KT * WPB <= 16 * BLOCK_SMALL && WPB <= BLOCK_SMALL && WPB % 64 == 0,
+                  "an LDS tile of at most 80 KB, whole wavefronts of worlds");
     StepConst k;
     k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K; k.Kc = 0;
     k.band2 = band2; k.band2_tight = band2_tight; k.obst = nullptr; k.obst64 = nullptr; k.quick = nullptr;
     k.touch[0] = k.touch[1] = k.touch[2] = k.touch[3] = 0;
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
-    for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
-         bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+    for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * WPB; bbase < N;
+         bbase += static_cast<int64_t>(gridDim.x) * WPB) {
         const int64_t i = bbase + threadIdx.x;
-        const bool valid = i < N;
-        const int64_t ic = valid ? i : N - 1;
-        const uint32_t off = static_cast<uint32_t>(ic - bbase);
+        const bool valid = (WPB == BLOCK_SMALL || threadIdx.x < WPB) && i < N;     // a lane with a world of its own
+        const int64_t tile_last = (bbase + WPB <= N ? bbase + WPB : N) - 1;
+        const int64_t ic = valid ? i : tile_last;          // the others shadow the tile's last world and write nothing
+        const uint32_t off = static_cast<uint32_t>(ic - bbase);                     // < WPB
         EnvState e{a.state[0 * ld + ic], a.state[1 * ld + ic], a.state[2 * ld + ic], a.state[3 * ld + ic],
                    a.state[4 * ld + ic], a.state[5 * ld + ic], a.state[6 * ld + ic], a.time[ic]};
         __syncthreads();                                   // (a block that iterates: the last tile's columns are no longer read)
+        if (WPB == BLOCK_SMALL || threadIdx.x < WPB) {
+#pragma unroll 8
+            for (int j = 0; j < KT; ++j) {
+                const int jj = j < a.K ? j : a.K - 1;      // uniform; 1 <= a.K <= KT
+                const float* const rb = t32 + (6 * jj) * tld + bbase;
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            const int jj = j < a.K ? j : a.K - 1;          // uniform; 1 <= a.K <= KT
-            const float* const rb = t32 + (6 * jj) * tld + bbase;
-#pragma unroll
-            for (int f = 0; f < 5; ++f) sh.rows[j * 5 + f][threadIdx.x] = rb[f * tld + off];
+                for (int f = 0; f < 5; ++f) sh.rows[j * 5 + f][threadIdx.x] = rb[f * tld + off];
+            }
         }
         __syncthreads();
         const WorldTable wt{t32 + bbase, t64 + bbase, tld, off};
@@ -1571,9 +1584,9 @@ __device__ __forceinline__ void rollout_tables_body(const StepArgs& a, const flo
             ObstF rows[KT];                                 // this step's copy of the lane's column
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
-                rows[j].cx = sh.rows[j * 5 + 0][threadIdx.x]; rows[j].cy = sh.rows[j * 5 + 1][threadIdx.x];
-                rows[j].hx = sh.rows[j * 5 + 2][threadIdx.x]; rows[j].hy = sh.rows[j * 5 + 3][threadIdx.x];
-                rows[j].r2 = sh.rows[j * 5 + 4][threadIdx.x]; rows[j].w = 1.0f;
+                rows[j].cx = sh.rows[j * 5 + 0][off]; rows[j].cy = sh.rows[j * 5 + 1][off];
+                rows[j].hx = sh.rows[j * 5 + 2][off]; rows[j].hy = sh.rows[j * 5 + 3][off];
+                rows[j].r2 = sh.rows[j * 5 + 4][off]; rows[j].w = 1.0f;
             }
             const bool knife = fast_step<true, QUICK_NEVER, KT>(after, m.h, m.w, m.chord, u0, u1, k, rew, code, &wt, rows) && valid && !pending;
             if (any_lane(knife)) {
@@ -1613,8 +1626,8 @@ template <int AK, int MODE>
 __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 3))) void rollout_tables_kernel(
     const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
 {
-    __shared__ RolloutTablesShared<8> sh;
-    rollout_tables_body<AK, MODE, 8>(a, t32, t64, tld, band2, band2_tight, sh);
+    __shared__ RolloutTablesShared<8, BLOCK_SMALL> sh;
+    rollout_tables_body<AK, MODE, 8, BLOCK_SMALL>(a, t32, t64, tld, band2, band2_tight, sh);
 }
 
 // tables of 9..16 rows: 80 KB of LDS per block, two blocks per CU
@@ -1622,8 +1635,25 @@ template <int AK, int MODE>
 __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(1, 2))) void rollout_tables16_kernel(
     const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
 {
-    __shared__ RolloutTablesShared<16> sh;
-    rollout_tables_body<AK, MODE, 16>(a, t32, t64, tld, band2, band2_tight, sh);
+    __shared__ RolloutTablesShared<16, BLOCK_SMALL> sh;
+    rollout_tables_body<AK, MODE, 16, BLOCK_SMALL>(a, t32, t64, tld, band2, band2_tight, sh);
+}
+
+// tables of 17..32 rows: 128 worlds per block; 33..64 rows: 64 worlds per block (one block per CU)
+template <int AK, int MODE>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(1, 2))) void rollout_tables32_kernel(
+    const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
+{
+    __shared__ RolloutTablesShared<32, 128> sh;
+    rollout_tables_body<AK, MODE, 32, 128>(a, t32, t64, tld, band2, band2_tight, sh);
+}
+
+template <int AK, int MODE>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(1, 2))) void rollout_tables64_kernel(
+    const StepArgs a, const float* __restrict__ t32, const double* __restrict__ t64, int64_t tld, float band2, float band2_tight)
+{
+    __shared__ RolloutTablesShared<64, 64> sh;
+    rollout_tables_body<AK, MODE, 64, 64>(a, t32, t64, tld, band2, band2_tight, sh);
 }
 
 // Masked reset against per-world tables.  A block reads the mask of RESET_SCAN worlds and compacts the selected ones
@@ -2396,7 +2426,8 @@ int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, c
     if (N == 0 || T == 0) return 0;
     a.action = actions; a.action_ld = action_ld; a.action_step_stride = action_step_stride;
     a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;
-    const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
+    const int worlds_per_block = K <= 16 ? BLOCK_SMALL : (K <= 32 ? 128 : 64);
+    const dim3 grid(grid_for(N, worlds_per_block, 4096)), block(BLOCK_SMALL);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define AQUA_ROLLOUT_TABLES_MODE(KERNEL, AK)                                                                                 \
         if (auto_reset == AQUA_RESET_NEXT_STEP)                                                                              \
@@ -2406,7 +2437,9 @@ int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, c
         else hipLaunchKernelGGL((KERNEL<AK, 0>), grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight);
 #define AQUA_ROLLOUT_TABLES(AK)                                                                                              \
     case AK:                                                                                                                 \
-        if (wide) { AQUA_ROLLOUT_TABLES_MODE(rollout_tables16_kernel, AK) }                                                  \
+        if (K > 32) { AQUA_ROLLOUT_TABLES_MODE(rollout_tables64_kernel, AK) }                                                \
+        else if (K > 16) { AQUA_ROLLOUT_TABLES_MODE(rollout_tables32_kernel, AK) }                                           \
+        else if (wide) { AQUA_ROLLOUT_TABLES_MODE(rollout_tables16_kernel, AK) }                                             \
         else { AQUA_ROLLOUT_TABLES_MODE(rollout_tables_kernel, AK) }                                                         \
         break;
     switch (action_kind) {

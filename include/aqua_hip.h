@@ -214,10 +214,10 @@ int aqua_rollout_tables_f32(const AquaParams* p, const float* tab32_dev, const d
                             uint64_t seed, uint64_t tick, const uint64_t* tick_base_dev, float* reward, uint8_t* term,
                             int64_t out_step_stride, uint64_t* done_bits, int64_t done_step_stride, float* obs_norm,
                             int auto_reset, int advance_tick, void* stream);
-/* aqua_rollout_fused_f32 with per-world tables of at most 16 rows: T steps in ONE launch, the state in registers and the
- * block's tables in LDS for the whole rollout (40 KB per 256-world block for up to 8 rows, 80 KB for 9..16; K > 16:
- * AQUA_E_INVALID -- use aqua_rollout_tables_f32).  Results are
- * identical to aqua_rollout_tables_f32 with the same arguments. */
+/* aqua_rollout_fused_f32 with per-world tables: T steps in ONE launch, the state in registers and the block's tables in
+ * LDS for the whole rollout (40 KB per block of 256 worlds for up to 8 rows; 80 KB for 9..16 rows, for 17..32 rows with
+ * 128 worlds per block and for 33..64 rows with 64).  Results are identical to aqua_rollout_tables_f32 with the same
+ * arguments. */
 int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,
                                   float r_max, int64_t N, int64_t env_offset, float* state, int64_t ld, int32_t* time, int64_t T,
                                   const void* actions, int action_kind, int64_t action_ld, int64_t action_step_stride,

@@ -481,13 +481,15 @@ def test_masked_reset_between_steps_does_not_delay_restarts(torch):
 
 
 def _random_tables(rng, n, K):
-    """[n][K][5] reference-format rows: circles (radius 2..10) and rectangles (5..15 x 5..15), some rows absent."""
+    """[n][K][5] reference-format rows: circles (radius 2..10) and rectangles (5..15 x 5..15), some rows absent.  Tables of
+    more than 16 rows hold smaller obstacles (sizes x sqrt(10 / K)), so that about half of a world stays free."""
     t = np.zeros((n, K, 5))
     t[:, :, 0:2] = rng.uniform(10, 90, (n, K, 2))
     kind = rng.randint(0, 2, (n, K)).astype(np.float64)
     t[:, :, 2] = kind
-    t[:, :, 3] = np.where(kind == 0, rng.uniform(2, 10, (n, K)), rng.uniform(5, 15, (n, K)))
-    t[:, :, 4] = np.where(kind == 0, 0.0, rng.uniform(5, 15, (n, K)))
+    scale = 1.0 if K <= 16 else (10.0 / K) ** 0.5
+    t[:, :, 3] = np.where(kind == 0, rng.uniform(2, 10, (n, K)), rng.uniform(5, 15, (n, K))) * scale
+    t[:, :, 4] = np.where(kind == 0, 0.0, rng.uniform(5, 15, (n, K)) * scale)
     t[:, :, 2] = np.where(rng.randint(0, 5, (n, K)) == 0, -1.0, t[:, :, 2])        # ~20 % absent rows
     return t
 
@@ -704,20 +706,16 @@ def test_per_world_tables_rollout_and_graph_equal_single_steps(torch, mode):
         assert torch.equal(fused.state, ref.state) and torch.equal(fused.time, ref.time)
         if actions != "stored":
             assert torch.equal(fgraph.state, ref.state) and torch.equal(fgraph.time, ref.time)
-    long_tables = _make(torch, 100, _random_tables(rng, 100, 17), seed=1, auto_reset=mode)
-    long_tables.reset()
-    with pytest.raises(NotImplementedError):
-        long_tables.rollout(T, fused=True)                 # more than 16 rows do not fit the LDS tile
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["none", "same_step", "next_step"])
-@pytest.mark.parametrize("K", [11, 16])
+@pytest.mark.parametrize("K", [11, 16, 17, 32, 41, 64])
 def test_long_per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mode):
-    """per-world tables of more than eight rows (aqua.py:56-68: a list of any length per env object): the one-launch-per-step
-    kernels against the oracle's step_tables / reset_tables in every restart mode (codes and markers bit-exact, restarted
-    worlds bit for bit, floats within 1e-5), and the fused rollout -- its 16-row LDS tile -- against those launches, bit
-    for bit, eagerly and as a replayed graph"""
-    n, T = 9000 + 5, 24
+    """per-world tables of more than eight rows (aqua.py:56-68: a list of any length per env object), up to the library's 64:
+    the one-launch-per-step kernels against the oracle's step_tables / reset_tables in every restart mode (codes and markers
+    bit-exact, restarted worlds bit for bit, floats within 1e-5), and the fused rollout -- its LDS tile of 16 rows x 256
+    worlds, 32 x 128 or 64 x 64 -- against those launches, bit for bit, eagerly and as a replayed graph"""
+    n, T = (9000 + 5, 24) if K <= 16 else (2300 + 5, 24)     # (ragged against every tile width: 256, 128, 64)
     rng = np.random.RandomState(100 + K)
     tables = _random_tables(rng, n, K)
     acts = torch.as_tensor(rng.randint(0, 3, (T, n)).astype(np.uint8)).cuda()
