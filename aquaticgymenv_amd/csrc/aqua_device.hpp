@@ -782,9 +782,12 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // repeat its last row) -- no memory round trip at all.  The rare serial scan falls back to the table in memory (`wt`).
 // ROWS == RESEED_SOA: the same, for a block that keeps the tables of ALL its worlds in LDS as [row][field][world] (the
 // fused per-world rollout: SOA_ROWS = 8 / 16 / 32 / 64 rows, SOA_STRIDE = 256 / 256 / 128 / 64 worlds per block): `rows`
-// points at the world's column, fields SOA_STRIDE floats apart.
+// points at the world's column, fields SOA_STRIDE floats apart.  SOA_SPLIT > 1: a world is re-seeded by SOA_SPLIT groups
+// of G lanes side by side; every group makes the same G attempts, each against its own SOA_ROWS / SOA_SPLIT rows, and the
+// hits are OR-ed across the groups before anything is decided (a pass over a long table is then SOA_SPLIT times
+// shorter; everything downstream is computed redundantly, and identically, by every group).
 constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5;
-template <int G, int ROWS = 0, int SOA_ROWS = 8, int SOA_STRIDE = 256>
+template <int G, int ROWS = 0, int SOA_ROWS = 8, int SOA_STRIDE = 256, int SOA_SPLIT = 1>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
                                                      const ObstF* rows = nullptr, QuickPtr quick = nullptr, int Kc = 0,
@@ -850,11 +853,14 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
         } else if constexpr (ROWS == RESEED_SOA) {
             // rows in flight at a time: two (as above) for short tables; eight for the long ones, whose pass is otherwise
             // 32 LDS round trips one behind the other (the block has registers to spare: it is alone on its CU)
-            constexpr int RS = SOA_ROWS >= 32 ? 8 : 2;
-            static_assert(SOA_ROWS % RS == 0, "whole batches of rows");
-            const float* const soa = reinterpret_cast<const float*>(rows);
+            static_assert(SOA_SPLIT >= 1 && G * SOA_SPLIT <= 64 && SOA_ROWS % SOA_SPLIT == 0, "whole groups, whole shares of the rows");
+            constexpr int MINE = SOA_ROWS / SOA_SPLIT;     // rows this lane's group tests
+            constexpr int RS = MINE >= 8 && SOA_ROWS >= 32 ? 8 : 2;
+            static_assert(MINE % RS == 0, "whole batches of rows");
+            const int share = SOA_SPLIT > 1 ? (lane & (G * SOA_SPLIT - 1)) / G : 0;
+            const float* const soa = reinterpret_cast<const float*>(rows) + share * (MINE * 5 * SOA_STRIDE);
 #pragma unroll
-            for (int h = 0; h < SOA_ROWS; h += RS) {
+            for (int h = 0; h < MINE; h += RS) {
                 int first_row = h;
                 asm volatile("" : "+v"(first_row));      // (as above: the reads stay next to their use)
                 const float* r = soa + first_row * 5 * SOA_STRIDE;
@@ -868,6 +874,16 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 uint32_t fg = hit_g, fb = hit_b;
                 asm volatile("" : "+v"(fg), "+v"(fb));
                 hit_g = fg != 0u; hit_b = fb != 0u;
+            }
+            if constexpr (SOA_SPLIT > 1) {                 // a candidate is hit if any group's share of the rows hits it
+                constexpr int GW = G * SOA_SPLIT;
+                uint64_t every = 0;                        // bit 0 of every group of the world
+#pragma unroll
+                for (int c = 0; c < SOA_SPLIT; ++c) every |= 1ull << (c * G);
+                const int wbase = lane & ~(GW - 1);
+                const uint64_t mg = __ballot(hit_g) >> wbase, mb = __ballot(hit_b) >> wbase;
+                hit_g = ((mg >> sub) & every) != 0ull;
+                hit_b = ((mb >> sub) & every) != 0ull;
             }
         } else if constexpr (ROWS == RESEED_WORLD) {
 #pragma unroll 1

@@ -1493,9 +1493,12 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
     first[0] = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.r.count[parity][w];
-    constexpr uint32_t PER_PASS = 64 / RESET_GROUP;
+    // a long table's rows are shared out over 4 or 8 groups of eight lanes (8 rows per lane and pass either way): one world
+    // of 64 rows, or two of 32, per wavefront and pass instead of eight -- a block of 64 worlds restarts one or two per step
+    constexpr int SPLIT = KT / 8 >= 4 ? KT / 8 : 1, WORLD_LANES = RESET_GROUP * SPLIT;
+    constexpr uint32_t PER_PASS = 64 / WORLD_LANES;
     for (uint32_t qb = static_cast<uint32_t>(server) * PER_PASS; qb < tk.n; qb += SERVERS * PER_PASS) {
-        const uint32_t q = qb + (lane / RESET_GROUP);
+        const uint32_t q = qb + (lane / WORLD_LANES);
         const bool active = q < tk.n;
         uint32_t seg = 0;
 #pragma unroll
@@ -1503,9 +1506,9 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
         const uint32_t owner = sh.r.list[parity][seg][active ? q - first[seg] : 0];
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
         const WorldTable own{t32_tile, nullptr, tld, owner};
-        const EnvState f = reset_env_group<RESET_GROUP, RESEED_SOA, KT, WPB>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
+        const EnvState f = reset_env_group<RESET_GROUP, RESEED_SOA, KT, WPB, SPLIT>(active, a.seed, world, tick, a.waves, a.random_boat, a.random_goal, a.K,
                                                                       nullptr, reinterpret_cast<const ObstF*>(&sh.rows[0][owner]), nullptr, 0, &own);
-        if (active && (lane & (RESET_GROUP - 1)) == 0) {
+        if (active && (lane & (WORLD_LANES - 1)) == 0) {
             float* r = sh.r.result[q];
             r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
         }
