@@ -180,6 +180,12 @@ def test_argument_validation_without_touching_a_device(capi):
     assert lib.aqua_rollout_f32(*rollout, 3, 0, None) == -1             # auto_reset outside 0..2
     assert lib.aqua_rollout_f32(*rollout, 0, 1, None) == -1             # advance_tick without a tick base
     assert b"advance_tick" in lib.aqua_last_error()
+    # the same entry with events attached to its first / last launch validates the same way, and T = 0 is a no-op
+    assert lib.aqua_rollout_events_f32(*rollout, 3, 0, None, None, None) == -1
+    assert lib.aqua_rollout_events_f32(*rollout, 0, 1, None, None, None) == -1
+    empty = list(rollout)
+    empty[8] = 0                                                         # T
+    assert lib.aqua_rollout_events_f32(*empty, 2, 0, None, None, None) == 0
     fused = [ctypes.byref(p), None, 0, 8, 0, addr, 8, addr, 4, addr, 0, 0, 0, 1, 0, None, addr, addr, 0]
     assert lib.aqua_rollout_fused_f32(*fused, 3, None) == -1            # auto_reset outside 0..2
     assert lib.aqua_event_record(None, None) == -1 and lib.aqua_event_destroy(None) == 0
