@@ -16,7 +16,10 @@ LIB = os.path.join(HERE, "lib", "libaqua_hip.so")
 ARCH = "gfx950"
 # -fno-honor-nans: no state ever holds a NaN; it drops the v_max(x, x) canonicalisation in front of every
 # fmin/fmax (results for non-NaN inputs are unchanged; contraction is controlled per function by pragmas)
-COMMON_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-shared", "-fPIC", "-fno-honor-nans"]
+# -cuid=...: clang derives the compilation-unit id it bakes into the fat binary's symbols from the source's absolute path
+# by default -- the same source built in another directory is then another file.  Fixed, the library's hash (the build
+# tag of bench.py and profiles/traffic.json) depends on the sources and this command line only.
+COMMON_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-shared", "-fPIC", "-fno-honor-nans", "-cuid=aqua_hip"]
 
 
 def hipcc_path():
