@@ -545,17 +545,44 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     store_outputs<VEC>(a, tile, off, rem, full, rew, code, done_mask, wb);
 
     // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
-    uint32_t skip_mask = 0;        // worlds whose fresh state is written by a re-seeding group
+    // worlds whose fresh state is written by a re-seeding group (their own lane skips its state stores)
+    const uint32_t skip_mask = (RESTART && a.auto_reset) ? done_mask : 0u;
     constexpr uint32_t own_reset_mask = 0;
+    if (RESTART && a.auto_reset) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (done_mask & (1u << j)) sh.list[atomicAdd(&sh.count, 1u)] = static_cast<uint16_t>(off + j);
+        }
+        AQUA_STAMP(4);      // outputs stored, list appended
+    }
+    // The lane's own state stores go out AHEAD of the barrier (behind the list append, which the barrier waits for):
+    // nothing behind it needs them, and the wavefronts that re-seed end with the restart stores only.
+    if (skip_mask == 0 && own_reset_mask == 0 && full) {
+        store_row<VEC, true>(row0 + 0 * ld, off, rem, x, wb);
+        store_row<VEC, true>(row0 + 1 * ld, off, rem, y, wb);
+        store_row<VEC, true>(row0 + 2 * ld, off, rem, th, wb);
+        store_row<VEC, true>(row0 + 5 * ld, off, rem, wx, wb);
+        store_row<VEC, true>(row0 + 6 * ld, off, rem, wy, wb);
+        store_row<VEC, true>(trow, off, rem, t, wb);
+        if (a.obs_norm != nullptr) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) write_norm(a, tile + off + j, x[j], y[j], th[j], gx[j], gy[j], wb);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t i = off + j;
+            if (!(skip_mask & (1u << j)) && static_cast<int64_t>(i) < rem) {
+                st1(row0 + 0 * ld + i, x[j], wb); st1(row0 + 1 * ld + i, y[j], wb); st1(row0 + 2 * ld + i, th[j], wb);
+                st1(row0 + 5 * ld + i, wx[j], wb); st1(row0 + 6 * ld + i, wy[j], wb);
+                st1(trow + i, t[j], wb);
+                write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j], wb);
+            }
+        }
+    }
     if (RESTART && a.auto_reset) {
         uint32_t* const cnt = &sh.count;
         uint16_t* const list = sh.list;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (done_mask & (1u << j)) list[atomicAdd(cnt, 1u)] = static_cast<uint16_t>(off + j);
-        }
-        skip_mask = done_mask;
-        AQUA_STAMP(4);      // outputs stored, list appended
         __syncthreads();
         AQUA_STAMP(5);      // barrier passed
         const uint32_t n_done = *cnt;
@@ -583,29 +610,6 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
     }
     AQUA_STAMP(6);          // group re-seeding done
 
-    if (skip_mask == 0 && own_reset_mask == 0 && full) {
-        store_row<VEC, true>(row0 + 0 * ld, off, rem, x, wb);
-        store_row<VEC, true>(row0 + 1 * ld, off, rem, y, wb);
-        store_row<VEC, true>(row0 + 2 * ld, off, rem, th, wb);
-        store_row<VEC, true>(row0 + 5 * ld, off, rem, wx, wb);
-        store_row<VEC, true>(row0 + 6 * ld, off, rem, wy, wb);
-        store_row<VEC, true>(trow, off, rem, t, wb);
-        if (a.obs_norm != nullptr) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) write_norm(a, tile + off + j, x[j], y[j], th[j], gx[j], gy[j], wb);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const uint32_t i = off + j;
-            if (!(skip_mask & (1u << j)) && static_cast<int64_t>(i) < rem) {
-                st1(row0 + 0 * ld + i, x[j], wb); st1(row0 + 1 * ld + i, y[j], wb); st1(row0 + 2 * ld + i, th[j], wb);
-                st1(row0 + 5 * ld + i, wx[j], wb); st1(row0 + 6 * ld + i, wy[j], wb);
-                st1(trow + i, t[j], wb);
-                write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j], wb);
-            }
-        }
-    }
     AQUA_RTSTAMP(7);        // state stores issued (wall clock)
 }
 
