@@ -786,7 +786,7 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // of G lanes side by side; every group makes the same G attempts, each against its own SOA_ROWS / SOA_SPLIT rows, and the
 // hits are OR-ed across the groups before anything is decided (a pass over a long table is then SOA_SPLIT times
 // shorter; everything downstream is computed redundantly, and identically, by every group).
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5;
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5, RESEED_HANDOFF16 = -6;
 template <int G, int ROWS = 0, int SOA_ROWS = 8, int SOA_STRIDE = 256, int SOA_SPLIT = 1>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
@@ -827,9 +827,9 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
             const float bdy2 = bdy * bdy;
             hit_b |= fmaf(bdx, bdx, bdy2) <= r2;
         };
-        if constexpr (ROWS > 0 || ROWS == RESEED_HANDOFF8) {   // `rows` is in LDS: a few rows in registers at a time
+        if constexpr (ROWS > 0 || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_HANDOFF16) {   // `rows` is in LDS: a few rows in registers at a time
             constexpr int RS = 2;                         // rows in registers at a time
-            constexpr int NROWS = ROWS > 0 ? ROWS : 8;
+            constexpr int NROWS = ROWS > 0 ? ROWS : (ROWS == RESEED_HANDOFF16 ? 16 : 8);
 #pragma unroll
             for (int h = 0; h < NROWS; h += RS) {
                 // (the index is laundered so that the reads stay here, next to their use, instead of being
@@ -946,7 +946,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_SOA) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_HANDOFF16 || ROWS == RESEED_SOA) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

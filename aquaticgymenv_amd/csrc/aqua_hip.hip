@@ -1161,10 +1161,11 @@ struct TablesShared {
 // table a second time -- a dependent round trip behind the step's traffic -- the same-step launch took 13.6-14.4 us and
 // the role-split next-step launch 14.4-15.0 (its re-seeding blocks need the rows of the worlds their scan finds).
 constexpr int HANDOFF_PER_WAVE = 8;
+template <int KREG>
 struct HandoffShared {
     uint32_t count[BLOCK_SMALL / 64];
     uint8_t world[BLOCK_SMALL / 64][HANDOFF_PER_WAVE];           // the slot's world (offset in the tile)
-    ObstF rows[BLOCK_SMALL / 64][HANDOFF_PER_WAVE][8];
+    ObstF rows[BLOCK_SMALL / 64][HANDOFF_PER_WAVE][KREG];
 };
 constexpr int TABLES_NEXT_STEP_TILE = 3;
 // MODE: AQUA_RESET_NONE, AQUA_RESET_SAME_STEP (restart inside the launch, below), AQUA_RESET_NEXT_STEP (the stepping
@@ -1175,7 +1176,7 @@ constexpr int TABLES_NEXT_STEP_TILE = 3;
 // uniform row base + the lane's 32-bit offset, forty loads in flight behind the nine of the state, one memory round trip
 // -- instead of two rows at a time after the move is known (three dependent round trips for eight rows, and 64-bit
 // per-lane addresses that cost the kernel 187 registers: two wavefronts per SIMD).
-constexpr int TABLES_KREG = 8;          // (HandoffShared holds eight rows per slot as well)
+constexpr int TABLES_KREG = 8, TABLES_KREG_WIDE = 16, TABLES_KREG_WIDE_MIN = 11;      // (HandoffShared<KREG>)
 template <int AK, int MODE, int KREG>
 __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
                                                   int64_t tld, float band2, float band2_tight, int64_t tile)
@@ -1276,7 +1277,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     }
     if constexpr ((RESTART || MODE == TABLES_NEXT_STEP_TILE) && KREG > 0) {
         // restart inside the tile, rows handed over through LDS (HandoffShared above)
-        __shared__ HandoffShared sh;
+        __shared__ HandoffShared<KREG> sh;
         constexpr int WAVES = BLOCK_SMALL / 64;
         const int wave = threadIdx.x >> 6;
         const bool want = RESTART ? done : (valid && tin == done_code(tick - 1));     // same-step: finished now; next-step: last tick
@@ -1290,7 +1291,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
                 const uint32_t slot = mine - lo;
                 sh.world[wave][slot] = static_cast<uint8_t>(threadIdx.x);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sh.rows[wave][slot][j] = rows[j];
+                for (int j = 0; j < KREG; ++j) sh.rows[wave][slot][j] = rows[j];
             }
             __syncthreads();
             uint32_t first[WAVES + 1], most = 0;
@@ -1313,7 +1314,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
                 const uint32_t slot = active ? q - first[seg] : 0u;
                 const uint32_t i = active ? sh.world[seg][slot] : 0u;                      // an idle group reads a world that exists
                 const WorldTable own{t32 + tile, nullptr, tld, i};
-                const EnvState f = reset_env_group<RESET_GROUP, RESEED_HANDOFF8>(
+                const EnvState f = reset_env_group<RESET_GROUP, KREG == 16 ? RESEED_HANDOFF16 : RESEED_HANDOFF8>(
                     active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
                     nullptr, &sh.rows[seg][slot][0], nullptr, 0, &own);
                 if (active && (lane & (RESET_GROUP - 1)) == 0) {
@@ -2294,9 +2295,15 @@ struct TableArgs {
 hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, hipStream_t s)
 {
     StepArgs a = a0;
-    const bool regs = a.K <= TABLES_KREG;               // the rows fit the lanes' registers (see tables_step_block)
-    // next-step restart: tables of up to eight rows restart inside the tile (rows handed over through LDS); longer ones
-    // keep the launch split by role (their re-seeding groups read the rows from memory)
+    // Tables of 11..16 rows with restarts take the 16-row instantiation (rows in registers, handed over through LDS like the
+    // eight-row one): us per step at 262 144 worlds, rows fetched again by the re-seeding groups -> handed over
+    // (profiles/r03/tables_kreg16.txt): 11 rows 18.9 -> 17.9, 12: 20.2 -> 18.6, 13: 21.9 -> 19.4, 14: 22.5 -> 20.4, 16: 24.7 ->
+    // 22.2 (same-step 26.0 -> 21.5).  It loads 16 rows whatever the table holds: 9 and 10 rows lose 2-4 %, and without
+    // restarts it is within 3 % either way -- both stay on the kernels that read the rows as they go.
+    const bool wide = a.K >= TABLES_KREG_WIDE_MIN && a.K <= TABLES_KREG_WIDE && a.auto_reset != 0;
+    const bool regs = a.K <= TABLES_KREG || wide;       // the rows fit the lanes' registers (see tables_step_block)
+    // next-step restart: tables whose rows are in registers restart inside the tile (rows handed over through LDS); the
+    // others keep the launch split by role (their re-seeding groups read the rows from memory)
     const bool ns_tile = a.auto_reset == AQUA_RESET_NEXT_STEP && regs;
     const bool ns = a.auto_reset == AQUA_RESET_NEXT_STEP && !regs;
     const bool interleave = ns && a.N >= NS_INTERLEAVE_MIN;
@@ -2310,7 +2317,9 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
 #define AQUA_TAB_ARGS grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight
 #define AQUA_TAB_LAUNCH(AK)                                                                                        \
     case AK:                                                                                                        \
-        if (ns_tile) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG>), AQUA_TAB_ARGS);        \
+        if (ns_tile && wide) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
+        else if (ns_tile) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG>), AQUA_TAB_ARGS);   \
+        else if (regs && wide && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
         else if (regs && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG>), AQUA_TAB_ARGS); \
         else if (regs) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, TABLES_KREG>), AQUA_TAB_ARGS);            \
         else if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true>), AQUA_TAB_ARGS);                           \
