@@ -162,9 +162,11 @@ def test_median_pick():
 def test_argument_checks():
     assert bench.parse(["--steps", "20", "--warmup", "5"]).steps == 20
     assert bench.parse([]).regions == bench.REGIONS
-    for bad in (["--steps", "0"], ["--warmup", "-1"], ["--regions", "0"]):
+    for bad in (["--steps", "0"], ["--warmup", "-1"], ["--regions", "0"], ["--region-clock", "auto"]):
         with pytest.raises(SystemExit):
             bench.parse(bad)
+    assert bench.parse([]).region_clock == "stream"          # the graph between two recorded stream events is the default clock
+    assert bench.parse(["--region-clock", "launch"]).region_clock == "launch"
 
 
 def test_traffic_is_null_without_a_matching_build(monkeypatch):

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""per-world obstacle tables of K rows (sized so that about a quarter of a world is blocked), 262 144 worlds, one launch per
+step as a replayed graph: us per step in the three restart modes.  usage: python tools/r03/tables_step_time.py K"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/bench.py') else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from aquaticgymenv_amd.batched import BatchedAqua
 n, K, steps = 262144, int(sys.argv[1]), 100
 rng = np.random.RandomState(7)
