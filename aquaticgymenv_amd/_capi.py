@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64
@@ -16,7 +16,7 @@ MAX_OBSTACLES = 64
 SYMBOLS = (
     "aqua_version", "aqua_last_error", "aqua_obstacle_blob_bytes", "aqua_pack_obstacles", "aqua_step_f32",
     "aqua_reset_f32", "aqua_rollout_f32", "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin",
-    "aqua_graph_end", "aqua_graph_launch", "aqua_graph_destroy",
+    "aqua_graph_end", "aqua_graph_launch", "aqua_graph_upload", "aqua_graph_destroy",
     "aqua_discrete_constants", "aqua_obs_norm_f32",
     "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
     "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
@@ -78,6 +78,7 @@ def _load():
     lib.aqua_graph_begin.argtypes = [vp]
     lib.aqua_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
     lib.aqua_graph_launch.argtypes = [vp, vp]
+    lib.aqua_graph_upload.argtypes = [vp, vp]
     lib.aqua_graph_destroy.argtypes = [vp]
     lib.aqua_event_create.argtypes = [ctypes.POINTER(vp)]
     lib.aqua_event_record.argtypes = [vp, vp]
@@ -97,7 +98,7 @@ def _load():
     lib.aqua_discrete_constants.restype = None
     for name in ("aqua_pack_obstacles", "aqua_step_f32", "aqua_reset_f32", "aqua_rollout_f32",
                  "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin", "aqua_graph_end",
-                 "aqua_graph_launch", "aqua_graph_destroy",
+                 "aqua_graph_launch", "aqua_graph_upload", "aqua_graph_destroy",
                  "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
                  "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",

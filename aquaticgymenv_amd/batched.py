@@ -94,6 +94,10 @@ class RolloutGraph(object):
         env._device_tick += self.steps
         return self.reward, self.term
 
+    def upload(self):
+        """hipGraphUpload on the current stream: the first launch() then finds the graph's device-side resources in place"""
+        _capi.check(_capi.lib.aqua_graph_upload(self._handle, self._env._stream()), "aqua_graph_upload")
+
     def elapsed_ms(self):
         """GPU time of the last replay between the graph's first and last node (capture_rollout(timing=True)); the
         stream must have been synchronised since."""

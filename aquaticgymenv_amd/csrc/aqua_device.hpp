@@ -621,17 +621,26 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
 // ------------------------------------------------------------------------------------ reset
 // float32 specification shared with nothing: oracle/aqua_oracle.c restates it independently and the
 // two are compared bit for bit.  Every rounding is explicit (fmaf or one operation per statement).
+// COLD: a path taken once in thousands of launches (the serial scan of reset_env_group): one row at a time.  Unrolled
+// and vectorised, that loop's preheader alone spilled fourteen SGPRs of the next-step kernel to VGPR lanes.
+template <bool COLD = false>
 __device__ __forceinline__ bool reset_hit(int K, ObstPtr t, float px, float py)
 {
 #pragma clang fp contract(off)
     bool hit = false;
-#pragma unroll 4
-    for (int j = 0; j < K; ++j) {
+    const auto test = [&](int j) {
         const float ax = fabsf(px - t[j].cx), ay = fabsf(py - t[j].cy);
         const float dx = fmaxf(ax - t[j].hx, 0.0f), dy = fmaxf(ay - t[j].hy, 0.0f);
         const float dy2 = dy * dy;
         const float d2 = fmaf(dx, dx, dy2);
         hit |= d2 <= t[j].r2;
+    };
+    if constexpr (COLD) {
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (int j = 0; j < K; ++j) test(j);
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) test(j);
     }
     return hit;
 }
@@ -951,7 +960,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;
                 } else {
-                    if (reset_hit(K, t, cx, cy)) continue;
+                    if (reset_hit<true>(K, t, cx, cy)) continue;
                 }
                 bx = cx; by = cy; bt = heading;
                 break;

@@ -73,6 +73,47 @@ struct StepArgs {
     uint64_t tick_bump;
 };
 
+// Kernel arguments of step_ns_kernel -- the benchmarked kernel -- alone.  As a StepArgs (~30 eight-byte fields of which
+// this kernel uses half, 64-bit sizes, the seven state rows as base + r * ld) its prologue held 62 argument SGPRs next to
+// the 32 of the quick table: 106 SGPRs, 37 of them spilled to VGPR lanes -- 80 v_readlane / v_writelane, 24 on the
+// stepping path, each a vector instruction on a path that is bound by vector issue (profiles/r04/isa/).  Here: only what
+// the two roles read, in the order they need it; the rows as seven pointers (an access is row pointer + the lane's 32-bit
+// byte offset, tile included: no address arithmetic on the scalar unit in front of the loads); 32-bit sizes (the host
+// splits batches of more than NS_LAUNCH_MAX_WORLDS worlds into several launches); whatever only a rare branch wants
+// (injected noise, the normalised observation, the tick housekeeping) behind the fields the prologue fetches and read by
+// that branch itself (kernarg_at()).
+struct NsArgs {
+    float* row[7];                       // x, y, theta, goal_x, goal_y, wave_x, wave_y
+    int32_t* time;
+    const void* action;                  // AQUA_ACT_F32X2: the vL row (the vR row: action_hi)
+    float* reward;
+    uint8_t* term;
+    uint64_t* done_bits;
+    const void* obst_blob;
+    const uint64_t* tick_base;
+    uint64_t seed, tick;
+    int64_t env_offset;
+    uint32_t N, reseed_blocks;
+    int32_t K, time_limit;
+    float W, sigma;
+    uint32_t flags;                      // waves | NS_RANDOM_BOAT | NS_RANDOM_GOAL | NS_HAS_NOISE | NS_HAS_NORM | NS_DONE_WORD_WB
+    uint32_t reserved;
+    // ---- read by the branches that want them, through the kernel-argument segment pointer
+    const float* action_hi;
+    const float* noise[2];
+    float* norm[5];
+    uint64_t* tick_copy_to;
+    uint64_t* tick_bump_to;
+    uint64_t tick_bump;
+};
+enum : uint32_t { NS_WAVES_MASK = 0xFFu, NS_RANDOM_BOAT = 1u << 8, NS_RANDOM_GOAL = 1u << 9, NS_HAS_NOISE = 1u << 10,
+                  NS_HAS_NORM = 1u << 11, NS_DONE_WORD_WB = 1u << 12 };
+// one launch addresses its worlds with 32-bit byte offsets into rows of up to 8-byte elements
+constexpr int64_t NS_LAUNCH_MAX_WORLDS = int64_t(1) << 28;
+
+__device__ __forceinline__ int args_waves(const StepArgs& a) { return a.waves; }
+__device__ __forceinline__ int args_waves(const NsArgs& a) { return static_cast<int>(a.flags & NS_WAVES_MASK); }
+
 // ------------------------------------------------------------------ vector load/store helpers
 // `p` is a wave-uniform row pointer already advanced to the tile, `off` the lane's element offset
 // inside the tile (32-bit), `rem` the number of valid elements from p on.  FULL tiles carry no guards:
@@ -169,12 +210,13 @@ __device__ __forceinline__ ObstPtr obstacle_rows(const void* blob)
     return (ObstPtr)(uintptr_t)(static_cast<const char*>(blob) + sizeof(ObstHeader));
 }
 
-template <int QUICK = QUICK_NEVER>
-__device__ __forceinline__ StepConst make_const(const StepArgs& a, ObstPtr obst)
+// (A: StepArgs, or the next-step kernel's own NsArgs)
+template <int QUICK = QUICK_NEVER, typename A>
+__device__ __forceinline__ StepConst make_const(const A& a, ObstPtr obst)
 {
     StepConst k;
     k.quick = nullptr;                  // (qc0 / qr0 are read only when quick is set)
-    k.W = a.W; k.sigma = a.sigma; k.waves = a.waves; k.time_limit = a.time_limit; k.K = a.K;
+    k.W = a.W; k.sigma = a.sigma; k.waves = args_waves(a); k.time_limit = a.time_limit; k.K = a.K;
     k.obst = obst;
     k.Kc = 0; k.band2 = 0.0f; k.band2_tight = 0.0f;
     k.touch[0] = k.touch[1] = k.touch[2] = k.touch[3] = 0;
@@ -279,7 +321,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 // AQUA_STAMPS == 2: only the wavefront-start (3) and wavefront-end (2) wall-clock stamps, to perturb less
 // AQUA_STAMPS == 3: those two, kept per launch for the last 32 launches (tools/r03/burst_timeline.py)
 #if AQUA_STAMPS == 3
-__device__ __forceinline__ uint64_t launch_tick(const StepArgs& a);
+template <typename A> __device__ __forceinline__ uint64_t launch_tick(const A& a);
 #define AQUA_STAMP(slot) do { } while (0)
 #define AQUA_RTSTAMP(slot)                                                                            \
     do {                                                                                              \
@@ -615,7 +657,8 @@ __device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k,
 
 // tick of this launch.  The device-resident base is written only by tick_kernel, between launches, so it
 // is read through the scalar path (constant address space) like the obstacle table.
-__device__ __forceinline__ uint64_t launch_tick(const StepArgs& a)
+template <typename A>
+__device__ __forceinline__ uint64_t launch_tick(const A& a)
 {
     if (a.tick_base == nullptr) return a.tick;
     return a.tick + *(const uint64_t __attribute__((address_space(4)))*)(uintptr_t)a.tick_base;
@@ -638,19 +681,27 @@ __device__ __forceinline__ void fetch_args(const StepArgs& a)
 // of a kernel's first block only, by one thread.  Its arguments are read from the kernel-argument segment right here,
 // through a laundered pointer: as ordinary uses of `a` the compiler hoists their loads into every block's prologue
 // and, with the SGPR file full, spills them to VGPR lanes there (StepArgs is the kernels' first parameter: offset 0).
+// A kernel argument read where it is used, through a pointer into the kernel-argument segment that the optimiser cannot
+// trace back to the kernel's parameter: the value occupies SGPRs inside the branch that wants it and nowhere else.
+template <typename T>
+__device__ __forceinline__ T kernarg_at(size_t off)
+{
+    using KernArg = const char __attribute__((address_space(4)))*;
+    KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const T __attribute__((address_space(4)))*)(kp + off);
+}
+
+template <typename A = StepArgs>
 __device__ __forceinline__ void tick_housekeeping()
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        using KernArg = const char __attribute__((address_space(4)))*;
-        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kp));
-        const auto word = [&](size_t off) { return *(const uint64_t __attribute__((address_space(4)))*)(kp + off); };
-        uint64_t* const copy_to = reinterpret_cast<uint64_t*>(word(offsetof(StepArgs, tick_copy_to)));
-        uint64_t* const bump_to = reinterpret_cast<uint64_t*>(word(offsetof(StepArgs, tick_bump_to)));
+        uint64_t* const copy_to = kernarg_at<uint64_t*>(offsetof(A, tick_copy_to));
+        uint64_t* const bump_to = kernarg_at<uint64_t*>(offsetof(A, tick_bump_to));
         if (copy_to != nullptr || bump_to != nullptr) {
-            const uint64_t base = *reinterpret_cast<const uint64_t*>(word(offsetof(StepArgs, tick_base)));
+            const uint64_t base = *kernarg_at<const uint64_t*>(offsetof(A, tick_base));
             if (copy_to != nullptr) st1(copy_to, base);
-            if (bump_to != nullptr) st1(bump_to, base + word(offsetof(StepArgs, tick_bump)));
+            if (bump_to != nullptr) st1(bump_to, base + kernarg_at<uint64_t>(offsetof(A, tick_bump)));
         }
     }
 }
@@ -715,23 +766,35 @@ struct NsReseedShared {
     uint16_t list[NS_MAIN_WAVES][NS_SCAN_ROWS * 64];
 };
 
+// the normalised observation of one world (see write_norm): the five row pointers are fetched here, by the launches that
+// have such a buffer
+__device__ __forceinline__ void ns_write_norm(const NsArgs& a, uint32_t byte_off, float x, float y, float th, float gx,
+                                              float gy, bool wb)
+{
+    if (!(a.flags & NS_HAS_NORM)) return;
+    const auto row = [](int r) { return kernarg_at<float*>(offsetof(NsArgs, norm) + sizeof(float*) * r); };
+    st_at(row(0), byte_off, x * 0.01f, wb);
+    st_at(row(1), byte_off, y * 0.01f, wb);
+    st_at(row(2), byte_off, fmaf(th, 0.15915494309189535f, 0.5f), wb);
+    st_at(row(3), byte_off, gx * 0.01f, wb);
+    st_at(row(4), byte_off, gy * 0.01f, wb);
+}
+
 // SMALL_TABLE: the launch has at most NS_TABLE_ROWS obstacles (decided on the host: one kernel per case keeps the
 // code each launch has to fetch short -- the instruction cache starts every launch cold)
 template <bool SMALL_TABLE, bool WB>
-__device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block, NsReseedShared& sh)
+__device__ __forceinline__ void ns_reseed_block(const NsArgs& a, uint32_t block, NsReseedShared& sh)
 {
     __builtin_amdgcn_s_setprio(3);                      // the longest chain of the launch: issue first
-    const int64_t base = block * NS_SCAN;
-    const int64_t ld = a.ld, rem = a.N - base;          // > 0
+    const uint32_t base = block * NS_SCAN;              // the block's first world; every access below is row pointer +
+    const uint32_t rem = a.N - base;                    // 32-bit byte offset (> 0)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t last = static_cast<uint32_t>(rem < NS_SCAN ? rem - 1 : NS_SCAN - 1);
-    float* const row0 = a.state + base;
-    int32_t* const trow = a.time + base;
+    const uint32_t last = (rem < NS_SCAN ? rem : static_cast<uint32_t>(NS_SCAN)) - 1u;
     int32_t tw[NS_SCAN_ROWS];
 #pragma unroll
     for (int j = 0; j < NS_SCAN_ROWS; ++j) {            // the loads first
         const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
-        tw[j] = ld1(trow + (i < last ? i : last));
+        tw[j] = ld_at(a.time, (base + (i < last ? i : last)) * 4u);
     }
     // Small tables (the usual case) are copied into LDS by the first lanes -- one vector load each, in flight with
     // the time row -- and the obstacle pass of the re-seeding reads them from there after the barrier below,
@@ -750,10 +813,9 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     for (int j = 0; j < NS_SCAN_ROWS; ++j) {            // wavefront-private compaction: ballot + prefix count
         const uint32_t i = static_cast<uint32_t>(j * NS_BLOCK) + threadIdx.x;
 #ifdef AQUA_NS_NOMAIN
-        const bool p = static_cast<int64_t>(i) < rem && tw[j] != restart &&
-                       ((static_cast<uint32_t>(base) + i) * 2654435761u + static_cast<uint32_t>(tick) * 40503u) % 54u == 0u;
+        const bool p = i < rem && tw[j] != restart && ((base + i) * 2654435761u + static_cast<uint32_t>(tick) * 40503u) % 54u == 0u;
 #else
-        const bool p = static_cast<int64_t>(i) < rem && tw[j] == restart;
+        const bool p = i < rem && tw[j] == restart;
 #endif
         const uint64_t m = __ballot(p);
         if (p) sh.list[wave][n_mine + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
@@ -775,6 +837,8 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
     const uint32_t n_pending = uni(first[NS_MAIN_WAVES]);
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
     AQUA_RTSTAMP(1);
+    const int waves = args_waves(a), random_boat = (a.flags & NS_RANDOM_BOAT) != 0, random_goal = (a.flags & NS_RANDOM_GOAL) != 0;
+    const uint64_t env_base = static_cast<uint64_t>(a.env_offset) + base;
     constexpr uint32_t PER_WAVE = 64 / NS_RESEED_GROUP, PER_BLOCK = NS_MAIN_WAVES * PER_WAVE;
     for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_pending; qb += PER_BLOCK) {
         const uint32_t q = qb + (lane / NS_RESEED_GROUP);
@@ -783,19 +847,20 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
 #pragma unroll
         for (int w = 1; w < NS_MAIN_WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
         const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
-        const uint64_t env = static_cast<uint64_t>(a.env_offset + base) + i;
+        const uint64_t env = env_base + i;
         EnvState e;
         if constexpr (SMALL_TABLE)
-            e = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst, sh.rows);
+            e = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env, tick, waves, random_boat, random_goal, k.K, k.obst, sh.rows);
         else
-            e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            e = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env, tick, waves, random_boat, random_goal, k.K, k.obst);
         if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
             constexpr bool wb = WB;
-            st1(row0 + 0 * ld + i, e.x, wb); st1(row0 + 1 * ld + i, e.y, wb); st1(row0 + 2 * ld + i, e.th, wb);
-            st1(row0 + 3 * ld + i, e.gx, wb); st1(row0 + 4 * ld + i, e.gy, wb);
-            st1(row0 + 5 * ld + i, e.wx, wb); st1(row0 + 6 * ld + i, e.wy, wb);
-            st1(trow + i, restart_code(tick), wb);
-            write_norm(a, base + i, e.x, e.y, e.th, e.gx, e.gy, wb);
+            const uint32_t i4 = (base + i) * 4u;
+            st_at(a.row[0], i4, e.x, wb); st_at(a.row[1], i4, e.y, wb); st_at(a.row[2], i4, e.th, wb);
+            st_at(a.row[3], i4, e.gx, wb); st_at(a.row[4], i4, e.gy, wb);
+            st_at(a.row[5], i4, e.wx, wb); st_at(a.row[6], i4, e.wy, wb);
+            st_at(a.time, i4, restart_code(tick), wb);
+            ns_write_norm(a, i4, e.x, e.y, e.th, e.gx, e.gy, wb);
         }
     }
     AQUA_RTSTAMP(2);
@@ -810,9 +875,9 @@ __device__ __forceinline__ void ns_reseed_block(const StepArgs& a, int64_t block
 // re-seeding blocks (latency-bound, three wavefronts of four busy, no memory traffic) before the first world is stepped,
 // and the two roles would no longer overlap: there one block in every five re-seeds, next to the four stepping blocks of
 // the same 1024 worlds (16.7 M worlds: 288 -> 195-215 us per step).  Returns false for the spare
-// blocks of a rounded-up grid.
+// blocks of a rounded-up grid.  role_index: the re-seeding block's number, or the stepping block's tile number.
 template <bool INTERLEAVE>
-__device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, int64_t& role_index)
+__device__ __forceinline__ bool ns_role(uint32_t reseed_blocks, uint32_t n_tiles, bool& reseed_role, uint32_t& role_index)
 {
     if constexpr (INTERLEAVE) {
         // Group g = the re-seeding block and the four stepping blocks of worlds [1024 g, 1024 g + 1024).  Blocks are dealt
@@ -824,12 +889,12 @@ __device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, in
         const uint32_t q = j / PER, member = j - q * PER;
         const uint32_t group = q * 8u + x;
         reseed_role = member == 0;
-        role_index = reseed_role ? static_cast<int64_t>(group) : static_cast<int64_t>(group) * (PER - 1) + (member - 1);
-        if (static_cast<int64_t>(group) >= a.reseed_blocks) return false;    // the grid is rounded up to whole sets of 8 groups
-        if (!reseed_role && role_index * NS_TILE >= a.N) return false;       // the last group may be short of stepping tiles
+        role_index = reseed_role ? group : group * (PER - 1) + (member - 1);
+        if (group >= reseed_blocks) return false;              // the grid is rounded up to whole sets of 8 groups
+        if (!reseed_role && role_index >= n_tiles) return false;   // the last group may be short of stepping tiles
     } else {
-        reseed_role = static_cast<int64_t>(blockIdx.x) < a.reseed_blocks;
-        role_index = reseed_role ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) - a.reseed_blocks;
+        reseed_role = blockIdx.x < reseed_blocks;
+        role_index = reseed_role ? blockIdx.x : blockIdx.x - reseed_blocks;
     }
     return true;
 }
@@ -837,18 +902,14 @@ __device__ __forceinline__ bool ns_role(const StepArgs& a, bool& reseed_role, in
 // INTERLEAVE: the grid layout (chosen on the host by batch size, like SMALL_TABLE: one kernel per case keeps the SGPR
 // file of the one-round case -- the benchmarked one -- exactly as tight as it was)
 template <int AK, bool SMALL_TABLE, bool INTERLEAVE, bool WB = false>
-__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void step_ns_kernel(const StepArgs a)
+__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void step_ns_kernel(const NsArgs a)
 {
     __shared__ NsReseedShared sh;
-    // Everything the prologue needs from the kernel-argument segment is fetched in ONE batch, ahead of the
-    // first wait: the draws then need no further scalar load (with the tick passed by value they start while
-    // the table header, issued behind the state loads, is still on its way).
-    fetch_args(a);
     AQUA_RTSTAMP(3);        // wavefront started
-    tick_housekeeping();
+    tick_housekeeping<NsArgs>();
     bool reseed_role;
-    int64_t role_index;
-    if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
+    uint32_t role_index;
+    if (!ns_role<INTERLEAVE>(a.reseed_blocks, (a.N + NS_TILE - 1) / NS_TILE, reseed_role, role_index)) return;
     if (reseed_role) {
 #ifndef AQUA_NS_NOWORK                       // (timing experiment: what the re-seeding blocks cost the launch)
         ns_reseed_block<SMALL_TABLE, WB>(a, role_index, sh);
@@ -858,47 +919,74 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
 #ifdef AQUA_NS_NOMAIN
     return;                                  // (timing experiment: the re-seeding blocks alone)
 #endif
-    // ---- stepping block.  Every load goes out first: the addresses need the kernel arguments only, while
-    // the table header and the tick base below cost another scalar-memory round trip.  One straight-line
-    // sequence for whole and ragged tiles (a lane past the end reads the tile's last world and never writes).
-    const int64_t tile = role_index * NS_TILE;
-    const int64_t ld = a.ld, rem = a.N - tile;
+    // ---- stepping block.  Every load goes out first: an address is a row pointer straight from the kernel arguments
+    // plus the lane's byte offset (tile included), while the table header and the tick base below cost another
+    // scalar-memory round trip.  One straight-line sequence for whole and ragged tiles (a lane past the end reads the
+    // tile's last world and never writes).
+    const uint32_t tile = role_index * NS_TILE;
+    const uint32_t rem = a.N - tile;                   // >= 1
     const int lane = threadIdx.x & 63;
-    float* const row0 = a.state + tile;
-    int32_t* const trow = a.time + tile;
-    const uint32_t last = static_cast<uint32_t>(rem < NS_TILE ? rem - 1 : NS_TILE - 1);    // rem >= 1
+    const uint32_t last = (rem < NS_TILE ? rem : static_cast<uint32_t>(NS_TILE)) - 1u;
     const uint32_t off = threadIdx.x;                  // < NS_TILE
-    const bool valid = static_cast<int64_t>(off) < rem;
-    const uint32_t o = off < last ? off : last;        // umin: still a small 32-bit lane offset (saddr + voffset loads)
+    const bool valid = off < rem;
+    const uint32_t o = tile + (off < last ? off : last);       // the lane's world: a 32-bit offset (saddr + voffset accesses)
     float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
     int32_t tin[1];
     int64_t araw[1] = {2};
     int aidx[1] = {2};
-    const uint32_t o4 = o * 4u;                         // < 1024: lane byte offset inside a float/int row
-    tin[0] = ld_at(trow, o4);
-    x[0] = ld_at(row0 + 0 * ld, o4); y[0] = ld_at(row0 + 1 * ld, o4); th[0] = ld_at(row0 + 2 * ld, o4);
-    gx[0] = ld_at(row0 + 3 * ld, o4); gy[0] = ld_at(row0 + 4 * ld, o4);
-    wx[0] = ld_at(row0 + 5 * ld, o4); wy[0] = ld_at(row0 + 6 * ld, o4);
-    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action) + tile, o);
-    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action) + tile, o4);
-    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action) + tile, o * 8u);
+    const uint32_t o4 = o * 4u;                         // byte offset inside a float / int row
+#ifndef AQUA_NS_STAGGER
+#define AQUA_NS_STAGGER 0
+#endif
+    // (experiment, profiles/r04/stagger/: half of the stepping wavefronts issue their loads BEHIND their draws, so that
+    // the launch's memory phase and its arithmetic phase overlap between the two halves)
+    bool late = false;
+#if AQUA_NS_STAGGER == 1 || AQUA_NS_STAGGER == 4
+    late = (role_index & 1u) != 0;
+#elif AQUA_NS_STAGGER == 2
+    late = (threadIdx.x & 64u) != 0;
+#elif AQUA_NS_STAGGER == 3
+    late = (role_index & 2u) != 0;
+#elif AQUA_NS_STAGGER >= 5
+#ifndef AQUA_NS_SLEEP
+#define AQUA_NS_SLEEP 6
+#endif
+    const uint32_t wv = uni(threadIdx.x) >> 6;
+    const uint32_t cls = AQUA_NS_STAGGER == 5 ? ((role_index + wv) & 3u) : (AQUA_NS_STAGGER == 6 ? (role_index & 3u) : wv);
+    late = cls != 0;
+#endif
+    const auto issue_loads = [&]() {
+    tin[0] = ld_at(a.time, o4);
+    x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
+    gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
+    wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
+    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
+    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
+    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
     else if constexpr (AK == AQUA_ACT_F32X2) {
-        avl[0] = ld_at(static_cast<const float*>(a.action) + tile, o4);
-        avr[0] = ld_at(static_cast<const float*>(a.action) + a.action_ld + tile, o4);
+        avl[0] = ld_at(static_cast<const float*>(a.action), o4);
+        avr[0] = ld_at(a.action_hi, o4);
     }
+    };
+#if AQUA_NS_STAGGER == 4
+    if (late) __builtin_amdgcn_s_sleep(12);
+    issue_loads();
+#else
+    if (!late) issue_loads();
+#endif
     constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;     // tables of up to 8 rows: the quick table (5.22 -> 5.08 us)
     const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick = launch_tick(a);
     AQUA_RTSTAMP(0);
     // The draws need no loaded value: they run in the shadow of the loads.
-    const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
-    if (__builtin_expect(a.noise == nullptr, 1)) {
+    const uint64_t env0 = (static_cast<uint64_t>(a.env_offset) + tile) + off;
+    if (__builtin_expect(!(a.flags & NS_HAS_NOISE), 1)) {
         uint32_t w0[1], w1[1];
         pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
         u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
     } else {                                           // injected noise (tests): loaded here, not up front, so that no
-        u0[0] = ld_at(a.noise + tile, o4);             // load of this rare path is outstanding across the draws
-        u1[0] = ld_at(a.noise + a.noise_ld + tile, o4);
+        u0[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise)), o4);             // load of this rare path is
+        u1[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise) + sizeof(float*)), o4);   // outstanding across the draws
         asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));   // waited for right here: see above
     }
     if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
@@ -907,6 +995,14 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
         if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
         else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
     }
+#if AQUA_NS_STAGGER >= 1 && AQUA_NS_STAGGER != 4
+    asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));
+#if AQUA_NS_STAGGER >= 5
+    if (cls == 2) __builtin_amdgcn_s_sleep(AQUA_NS_SLEEP);
+    if (cls == 3) __builtin_amdgcn_s_sleep(2 * AQUA_NS_SLEEP);
+#endif
+    if (late) issue_loads();
+#endif
     asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));   // scheduling fence, see hold_loads()
     hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
     AQUA_RTSTAMP(4);        // draws done, loads back
@@ -936,31 +1032,34 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     }
     if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
     const bool done = code != 0u;
-    // The stores' own copies of the lane offset.  With the loads' o4 the seven row addresses are common
-    // subexpressions of the loads' and are kept, as 64-bit VGPR pairs formed by v_lshl_add_u64, from the top of
-    // the block to here; a value the optimiser cannot match to it leaves base + offset to be formed where it is
-    // used, and there it is the store's own SGPR base + 32-bit VGPR offset addressing: no instruction at all.
+    // The stores' own copies of the lane offset.  With the loads' o4 the row addresses are common subexpressions of
+    // the loads' and are kept, as 64-bit VGPR pairs formed by v_lshl_add_u64, from the top of the block to here; a
+    // value the optimiser cannot match to it leaves base + offset to be formed where it is used, and there it is the
+    // store's own SGPR base + 32-bit VGPR offset addressing: no instruction at all.
     uint32_t s4 = o4, s1 = o;
     asm volatile("" : "+v"(s4), "+v"(s1));
     constexpr bool wb = WB;                             // batches of millions of worlds only (STORE_WB_*)
     if (valid) {
-        st_at(a.reward + tile, s4, rew, wb);
-        st_at(a.term + tile, s1, static_cast<uint8_t>(code), wb);
+        st_at(a.reward, s4, rew, wb);
+        st_at(a.term, s1, static_cast<uint8_t>(code), wb);
     }
     if (a.done_bits != nullptr) {
         const uint64_t b = __ballot(done);
-        const int64_t word = (tile + (threadIdx.x & ~63u)) / 64;
-        if (lane == 0 && word < ((a.N + 63) >> 6)) store_done_word(a.done_bits + word, b, a.N);
+        const uint32_t word = (tile >> 6) + (uni(off) >> 6);                    // the wavefront's word: scalar
+        if (word < ((a.N + 63u) >> 6) && lane == 0) {
+            if (a.flags & NS_DONE_WORD_WB) a.done_bits[word] = b;               // (store_done_word(): the policy is the host's)
+            else st1(a.done_bits + word, b);
+        }
     }
     if (live) {                                        // pending worlds are written by the re-seeding blocks
-        st_at(row0 + 0 * ld, s4, e.x, wb); st_at(row0 + 1 * ld, s4, e.y, wb); st_at(row0 + 2 * ld, s4, e.th, wb);
-        st_at(row0 + 5 * ld, s4, e.wx, wb); st_at(row0 + 6 * ld, s4, e.wy, wb);
+        st_at(a.row[0], s4, e.x, wb); st_at(a.row[1], s4, e.y, wb); st_at(a.row[2], s4, e.th, wb);
+        st_at(a.row[5], s4, e.wx, wb); st_at(a.row[6], s4, e.wy, wb);
 #ifdef AQUA_NS_NOWORK
-        st_at(trow, s4, e.t, wb);
+        st_at(a.time, s4, e.t, wb);
 #else
-        st_at(trow, s4, done ? done_code(tick) : e.t, wb);
+        st_at(a.time, s4, done ? done_code(tick) : e.t, wb);
 #endif
-        write_norm_at(a, tile, s4, e.x, e.y, e.th, gx[0], gy[0], wb);
+        ns_write_norm(a, s4, e.x, e.y, e.th, gx[0], gy[0], wb);
     }
     AQUA_RTSTAMP(2);
 }
@@ -1392,8 +1491,9 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
     __shared__ ResetShared sh;
     tick_housekeeping();
     bool reseed_role;
-    int64_t role_index;
-    if (!ns_role<INTERLEAVE>(a, reseed_role, role_index)) return;
+    uint32_t role;
+    if (!ns_role<INTERLEAVE>(static_cast<uint32_t>(a.reseed_blocks), static_cast<uint32_t>((a.N + NS_TILE - 1) / NS_TILE), reseed_role, role)) return;
+    const int64_t role_index = role;
     if (!reseed_role) {
 #ifndef AQUA_NS_NOMAIN                       // (timing experiment: the re-seeding blocks alone, on a synthetic pending set)
         tables_step_block<AK, AQUA_RESET_NEXT_STEP, 0>(a, t32, t64, tld, band2, band2_tight, role_index * NS_TILE);
@@ -1825,6 +1925,17 @@ __global__ __launch_bounds__(BLOCK_SMALL) void obs_norm_kernel(const float* __re
 // ------------------------------------------------------------------ host side
 thread_local char g_err[512] = "";
 
+// The launch tables below name every action kind after AQUA_ACT_U8 through this macro.  Development builds only
+// (-DAQUA_DEV_U8_ONLY, never the shipped library): one action kind instead of seven, a sixth of the compile time while a
+// kernel is being worked on; the other kinds then fail with hipErrorInvalidValue.
+#ifdef AQUA_DEV_U8_ONLY
+#define AQUA_DEV_OTHER_KINDS(LAUNCH)
+#else
+#define AQUA_DEV_OTHER_KINDS(LAUNCH)                                                                       \
+    LAUNCH(AQUA_ACT_I32) LAUNCH(AQUA_ACT_I64) LAUNCH(AQUA_ACT_F32X2) LAUNCH(AQUA_ACT_SAMPLE_D) LAUNCH(AQUA_ACT_SAMPLE_C) \
+    LAUNCH(AQUA_ACT_BEARING)
+#endif
+
 int fail(int code, const char* fmt, ...)
 {
     va_list ap;
@@ -1914,27 +2025,41 @@ hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s, const LaunchE
         break;
     switch (kind) {
         AQUA_STEP_LAUNCH(AQUA_ACT_U8)
-        AQUA_STEP_LAUNCH(AQUA_ACT_I32)
-        AQUA_STEP_LAUNCH(AQUA_ACT_I64)
-        AQUA_STEP_LAUNCH(AQUA_ACT_F32X2)
-        AQUA_STEP_LAUNCH(AQUA_ACT_SAMPLE_D)
-        AQUA_STEP_LAUNCH(AQUA_ACT_SAMPLE_C)
-        AQUA_STEP_LAUNCH(AQUA_ACT_BEARING)
+        AQUA_DEV_OTHER_KINDS(AQUA_STEP_LAUNCH)
         default: return hipErrorInvalidValue;
     }
 #undef AQUA_STEP_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s, const LaunchEvents& ev = {})
+// One next-step launch over worlds [first, first + n) of the caller's batch (n <= NS_LAUNCH_MAX_WORLDS, first a multiple of
+// NS_SCAN): StepArgs -> the kernel's own NsArgs, pointers advanced to the range.
+hipError_t launch_step_ns_range(const StepArgs& a0, int kind, int64_t first, int64_t n, bool interleave, bool wb, bool housekeeping_head,
+                                bool housekeeping_tail, hipStream_t s, const LaunchEvents& ev)
 {
-    StepArgs a = a0;
-    a.reseed_blocks = (a.N + NS_SCAN - 1) / NS_SCAN;
-    const bool interleave = a.N >= NS_INTERLEAVE_MIN;
-    const bool wb = a.N >= STORE_WB_NEXT_STEP_MIN && a.N <= STORE_WB_NEXT_STEP_MAX;      // implies interleave
-    const int64_t tiles = interleave ? (a.reseed_blocks + 7) / 8 * 8 * (NS_SCAN / NS_TILE + 1)
-                                     : (a.N + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
-    if (tiles > MAX_GRID) return hipErrorInvalidValue;
+    NsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int r = 0; r < 7; ++r) a.row[r] = a0.state + r * a0.ld + first;
+    a.time = a0.time + first;
+    const size_t esz = action_elem_bytes(kind);
+    a.action = a0.action ? static_cast<const char*>(a0.action) + static_cast<size_t>(first) * esz : nullptr;
+    a.action_hi = (kind == AQUA_ACT_F32X2 && a0.action) ? static_cast<const float*>(a0.action) + a0.action_ld + first : nullptr;
+    a.reward = a0.reward + first;
+    a.term = a0.term + first;
+    a.done_bits = a0.done_bits ? a0.done_bits + first / 64 : nullptr;
+    a.obst_blob = a0.obst_blob; a.tick_base = a0.tick_base; a.seed = a0.seed; a.tick = a0.tick;
+    a.env_offset = a0.env_offset + first;
+    a.N = static_cast<uint32_t>(n);
+    a.reseed_blocks = static_cast<uint32_t>((n + NS_SCAN - 1) / NS_SCAN);
+    a.K = a0.K; a.time_limit = a0.time_limit; a.W = a0.W; a.sigma = a0.sigma;
+    a.flags = (static_cast<uint32_t>(a0.waves) & NS_WAVES_MASK) | (a0.random_boat ? NS_RANDOM_BOAT : 0u) | (a0.random_goal ? NS_RANDOM_GOAL : 0u);
+    if (a0.noise != nullptr) { a.flags |= NS_HAS_NOISE; a.noise[0] = a0.noise + first; a.noise[1] = a0.noise + a0.noise_ld + first; }
+    if (a0.obs_norm != nullptr) { a.flags |= NS_HAS_NORM; for (int r = 0; r < 5; ++r) a.norm[r] = a0.obs_norm + r * a0.ld + first; }
+    if (a0.N > DONE_WORD_WRITE_THROUGH_MAX_WORLDS) a.flags |= NS_DONE_WORD_WB;       // (store_done_word(): by the BATCH's size)
+    if (housekeeping_head) a.tick_copy_to = a0.tick_copy_to;         // see tick_housekeeping(): block 0 of ONE launch per step
+    if (housekeeping_tail) { a.tick_bump_to = a0.tick_bump_to; a.tick_bump = a0.tick_bump; }
+    const int64_t tiles = interleave ? (static_cast<int64_t>(a.reseed_blocks) + 7) / 8 * 8 * (NS_SCAN / NS_TILE + 1)
+                                     : (n + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
     const bool small = NS_TABLE_ROWS > 0 && a.K <= NS_TABLE_ROWS;
 #define AQUA_NS_LAUNCH(AK)                                                                           \
@@ -1948,16 +2073,29 @@ hipError_t launch_step_ns(const StepArgs& a0, int kind, hipStream_t s, const Lau
         break;
     switch (kind) {
         AQUA_NS_LAUNCH(AQUA_ACT_U8)
-        AQUA_NS_LAUNCH(AQUA_ACT_I32)
-        AQUA_NS_LAUNCH(AQUA_ACT_I64)
-        AQUA_NS_LAUNCH(AQUA_ACT_F32X2)
-        AQUA_NS_LAUNCH(AQUA_ACT_SAMPLE_D)
-        AQUA_NS_LAUNCH(AQUA_ACT_SAMPLE_C)
-        AQUA_NS_LAUNCH(AQUA_ACT_BEARING)
+        AQUA_DEV_OTHER_KINDS(AQUA_NS_LAUNCH)
         default: return hipErrorInvalidValue;
     }
 #undef AQUA_NS_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t launch_step_ns(const StepArgs& a, int kind, hipStream_t s, const LaunchEvents& ev = {})
+{
+    // layout and store policy follow the BATCH, not the launch: a batch of more than NS_LAUNCH_MAX_WORLDS worlds is a few
+    // launches of that many (their offsets inside a row must fit 32 bits), each with the kernels of its whole
+    const bool interleave = a.N >= NS_INTERLEAVE_MIN;
+    const bool wb = a.N >= STORE_WB_NEXT_STEP_MIN && a.N <= STORE_WB_NEXT_STEP_MAX;      // implies interleave
+    for (int64_t first = 0; first < a.N; first += NS_LAUNCH_MAX_WORLDS) {
+        const int64_t n = a.N - first < NS_LAUNCH_MAX_WORLDS ? a.N - first : NS_LAUNCH_MAX_WORLDS;
+        const bool head = first == 0, tail = first + n == a.N;
+        LaunchEvents e;
+        if (head) e.start = ev.start;
+        if (tail) e.stop = ev.stop;
+        const hipError_t rc = launch_step_ns_range(a, kind, first, n, interleave, wb, head, tail, s, e);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_step_any(const StepArgs& a, int kind, hipStream_t s, const LaunchEvents& ev = {})
@@ -2214,12 +2352,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
         break;
     switch (action_kind) {
         AQUA_ROLLOUT_LAUNCH(AQUA_ACT_U8)
-        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_I32)
-        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_I64)
-        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_F32X2)
-        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_SAMPLE_D)
-        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_SAMPLE_C)
-        AQUA_ROLLOUT_LAUNCH(AQUA_ACT_BEARING)
+        AQUA_DEV_OTHER_KINDS(AQUA_ROLLOUT_LAUNCH)
 #undef AQUA_ROLLOUT_LAUNCH
 #undef AQUA_ROLLOUT_MODE
         default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
@@ -2329,12 +2462,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
         break;
     switch (kind) {
         AQUA_TAB_LAUNCH(AQUA_ACT_U8)
-        AQUA_TAB_LAUNCH(AQUA_ACT_I32)
-        AQUA_TAB_LAUNCH(AQUA_ACT_I64)
-        AQUA_TAB_LAUNCH(AQUA_ACT_F32X2)
-        AQUA_TAB_LAUNCH(AQUA_ACT_SAMPLE_D)
-        AQUA_TAB_LAUNCH(AQUA_ACT_SAMPLE_C)
-        AQUA_TAB_LAUNCH(AQUA_ACT_BEARING)
+        AQUA_DEV_OTHER_KINDS(AQUA_TAB_LAUNCH)
         default: return hipErrorInvalidValue;
     }
 #undef AQUA_TAB_LAUNCH
@@ -2460,12 +2588,7 @@ int aqua_rollout_tables_fused_f32(const AquaParams* p, const float* tab32_dev, c
         break;
     switch (action_kind) {
         AQUA_ROLLOUT_TABLES(AQUA_ACT_U8)
-        AQUA_ROLLOUT_TABLES(AQUA_ACT_I32)
-        AQUA_ROLLOUT_TABLES(AQUA_ACT_I64)
-        AQUA_ROLLOUT_TABLES(AQUA_ACT_F32X2)
-        AQUA_ROLLOUT_TABLES(AQUA_ACT_SAMPLE_D)
-        AQUA_ROLLOUT_TABLES(AQUA_ACT_SAMPLE_C)
-        AQUA_ROLLOUT_TABLES(AQUA_ACT_BEARING)
+        AQUA_DEV_OTHER_KINDS(AQUA_ROLLOUT_TABLES)
 #undef AQUA_ROLLOUT_TABLES
 #undef AQUA_ROLLOUT_TABLES_MODE
         default: return fail(AQUA_E_INVALID, "unknown action_kind %d", action_kind);
@@ -2545,6 +2668,13 @@ int aqua_graph_launch(AquaGraph* g, void* stream)
     if (g == nullptr) return fail(AQUA_E_INVALID, "graph is NULL");
     const hipError_t e = hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : hip_fail(e, "hipGraphLaunch");
+}
+
+int aqua_graph_upload(AquaGraph* g, void* stream)
+{
+    if (g == nullptr) return fail(AQUA_E_INVALID, "graph is NULL");
+    const hipError_t e = hipGraphUpload(g->exec, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : hip_fail(e, "hipGraphUpload");
 }
 
 int aqua_graph_destroy(AquaGraph* g)
@@ -2633,6 +2763,9 @@ int aqua_ipc_buffer_create(size_t bytes, AquaIpcBuffer** out)
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc (ipc buffer)");
     if ((e = hipMemset(p, 0, bytes)) != hipSuccess) { (void)hipFree(p); return hip_fail(e, "hipMemset (ipc buffer)"); }
+    // the handle is exported next and other PROCESSES then write through streams nothing orders behind this memset on the
+    // null stream: it must have run before anybody can know the buffer (set-up code, not the hot path)
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) { (void)hipFree(p); return hip_fail(e, "hipStreamSynchronize (ipc buffer)"); }
     *out = new AquaIpcBuffer{p, bytes};
     return 0;
 }

@@ -64,9 +64,25 @@ def parse(argv=None):
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the done-mask exchange (side streams) even on one GPU: rehearsal of the N > 1 path")
-    ap.add_argument("--exchange", choices=("auto", "ipc", "rccl"), default="auto",
+    ap.add_argument("--exchange", choices=("auto", "ipc", "rccl", "none"), default="auto",
                     help="transport of the done-mask exchange: peer copies into IPC-mapped receive buffers (no kernel on the "
-                         "compute units), RCCL's all-gather, or auto = ipc when the ranks can map each other, else rccl")
+                         "compute units), RCCL's all-gather, auto = ipc when the ranks can map each other and a probe block "
+                         "arrives, else rccl, else none; none = the step path alone (the line says so: "
+                         "config.done_mask_exchange false)")
+    ap.add_argument("--exchange-note", default=None,
+                    help="(set by bench.py's own self-launch when it starts fresh ranks after a failed attempt: what failed; "
+                         "copied into config.done_mask_exchange_note)")
+    ap.add_argument("--soft-deadline", type=float, default=45.0,
+                    help="seconds the IPC set-up + probe may take before every rank drops it and goes on with the next "
+                         "transport (sharded.open_exchange)")
+    ap.add_argument("--setup-deadline", type=float, default=150.0,
+                    help="N > 1: seconds from the rendezvous to the end of the exchange's set-up; past it the rank writes one "
+                         "line to stderr and exits with status 3 (sharded.Watchdog) -- a stalled collective or copy becomes a "
+                         "bounded failure instead of a hang")
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0, help="N > 1: timeout of init_process_group")
+    ap.add_argument("--launch-deadline", type=float, default=330.0,
+                    help="self-launch (bare `bench.py --gpus N`): seconds the first set of ranks may take (a fresh box spends "
+                         "1-2 minutes importing torch); the fresh ranks of a fallback get 150 s")
     ap.add_argument("--copy-engine", choices=("auto", "waves", "dma"), default="auto",
                     help="--exchange ipc: copy by single-wavefront workgroups, by hipMemcpyAsync, or auto = wavefronts into "
                          "the own buffer and hipMemcpyAsync (the copy engines) into the other GPUs' buffers")
@@ -171,6 +187,21 @@ class StepRunner(object):
                 if key not in self.graphs:
                     self.graphs[key] = self.env.capture_rollout(s, actions=self.actions, keep_all=False, done_history=done)
 
+    def upload_unplayed(self, timed_steps, played):
+        """hipGraphUpload for the graphs of a region of timed_steps steps that none of the `played` run lengths replays;
+        -> how many were uploaded"""
+        if not self.use_graph:
+            return 0
+        seen = set(seg[:3] for n in played for seg in self.plan(n))
+        todo = []
+        for seg in self.plan(timed_steps):
+            if seg[:3] not in seen:
+                seen.add(seg[:3])
+                todo.append(seg[:3])
+        for key in todo:
+            self.graphs[key].upload()
+        return len(todo)
+
     def region_is_timed_graph(self, n_steps):
         plan = self.plan(n_steps)
         return self.use_graph and len(plan) == 1 and plan[0][:3] in self.timed
@@ -237,6 +268,17 @@ class StepRunner(object):
     @property
     def launch(self):
         return "hipGraph" if self.use_graph else "eager"
+
+
+def warmup_runs(warmup, steps):
+    """The warm-up budget as run lengths.  A captured graph's FIRST launch costs extra (region 0 of round 3's driver line:
+    9.3 us per step against 5.5 in the other four), so the warm-up replays the timed region's own graphs where its budget
+    allows -- warmup >= steps: whole regions of `steps` steps, then the remainder -- and otherwise the timed graphs are
+    uploaded ahead of time (StepRunner.upload_unplayed: hipGraphUpload).  Exactly `warmup` steps either way."""
+    if warmup >= steps > 0:
+        q, r = divmod(warmup, steps)
+        return [steps] * q + ([r] if r else [])
+    return [warmup] if warmup else []
 
 
 def pick_median(values):
@@ -380,11 +422,83 @@ def launch_command(gpus, argv, port, python=None, script=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
 
 
+FALLBACK_DEADLINE_S = 150.0
+
+
+def fallback_chain(exchange, one_gpu):
+    """transports bench.py's self-launch tries in turn, each with FRESH ranks: only `auto` falls back"""
+    if exchange != "auto":
+        return [exchange]
+    return ["auto", "none"] if one_gpu else ["auto", "rccl", "none"]
+
+
+def argv_with(argv, exchange, note):
+    """argv with --exchange / --exchange-note replaced"""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in ("--exchange", "--exchange-note"):
+            skip = True
+            continue
+        if a.startswith("--exchange=") or a.startswith("--exchange-note="):
+            continue
+        out.append(a)
+    out += ["--exchange", exchange]
+    if note:
+        out += ["--exchange-note", note]
+    return out
+
+
+def run_ranks(cmd, env, deadline_s, out=None, err=None):
+    """Start `cmd` as a fresh child in a session of its own and wait at most deadline_s for it.
+    -> (status, first JSON line or None, timed out).  Everything else the child prints on stdout goes to stderr.  Past the
+    deadline the child's whole process group (the launcher and its ranks: the group it leads, by number) is killed."""
+    import signal
+    import subprocess
+    import threading
+    out, err = out or sys.stdout, err or sys.stderr
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines = []
+
+    def pump():
+        for line in proc.stdout:                        # rank 0's line goes to stdout, everything else to stderr
+            if line.startswith("{") and not lines:
+                lines.append(line)
+            else:
+                err.write(line)
+                err.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    timed_out = False
+    try:
+        status = proc.wait(timeout=deadline_s)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)                # the session we created: its leader's pid IS the group's number
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        status = proc.wait()
+    t.join(timeout=5)
+    return status, (lines[0] if lines else None), timed_out
+
+
 def self_launch(args, argv, device_count=None, run=None):
     """Start the ranks as a FRESH child process (never a re-exec: this process may not replace itself once anything has
     touched the GPU, and the children must initialise HIP themselves), relay rank 0's JSON line, return the children's
-    status.  Refuses, with a message and a non-zero status, when the box has fewer GPUs than ranks."""
-    import subprocess
+    status.  Refuses, with a message and a non-zero status, when the box has fewer GPUs than ranks.
+    With --exchange auto a set of ranks that exits non-zero, or is still running at its deadline, is followed ONCE by fresh
+    ranks with --exchange rccl and then ONCE with --exchange none (the step path alone; the line then carries
+    config.done_mask_exchange false and the failures in done_mask_exchange_note): the first line that arrives is relayed
+    and its ranks' status returned -- first contact with a node cannot end without a line because a transport misbehaved."""
     if device_count is None:
         import torch
         device_count = torch.cuda.device_count()       # does not initialise HIP on this image
@@ -399,38 +513,29 @@ def self_launch(args, argv, device_count=None, run=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = launch_command(args.gpus, argv, free_port())
-    if run is not None:
-        return run(cmd, env)
-    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:                            # rank 0's line goes to stdout, everything else to stderr
-        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
-        sys.stdout.flush()
-    return proc.wait()
+    run = run or run_ranks
+    failures, status = [], 1
+    chain = fallback_chain(args.exchange, args.ranks_on_one_gpu)
+    for i, exchange in enumerate(chain):
+        note = "; ".join(failures) or args.exchange_note
+        cmd = launch_command(args.gpus, argv_with(argv, exchange, note) if (i or note) else argv, free_port())
+        deadline = args.launch_deadline if i == 0 else min(args.launch_deadline, FALLBACK_DEADLINE_S)
+        status, line, timed_out = run(cmd, env, deadline)
+        if line is not None:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            return status
+        failures.append("--exchange %s: %s" % (exchange, ("no line after %g s (ranks killed)" % deadline) if timed_out
+                                                else "ranks exited with status %d and no line" % status))
+        sys.stderr.write("bench.py: %s%s\n" % (failures[-1], "; starting fresh ranks with --exchange %s" % chain[i + 1]
+                                                if i + 1 < len(chain) else ""))
+    return status or 1
 
 
 # ------------------------------------------------------------------ the done-mask exchange of this run
 def exchange_blocks(n_steps, chunk, block_rows):
     """done-mask blocks a region of n_steps publishes (kind="ipc" needs that many receive slots between two fences)"""
     return sum(1 for seg in plan_region(n_steps, chunk, block_rows) if seg[3])
-
-
-def make_exchange(kind, block_rows, words, dev, slots, rank, world, torch, DoneMaskExchange, copy_engine="auto"):
-    """-> (exchange, kind used, note).  kind "auto": peer copies through IPC-mapped buffers when every rank can map every
-    other rank's buffer AND a probe block arrives intact everywhere, else RCCL's all-gather."""
-    note = None
-    if kind in ("auto", "ipc"):
-        # setup and probe agree across the ranks before they return or raise (sharded.DoneMaskExchange._agree): either every
-        # rank uses the mapped buffers or every rank falls back -- a one-sided fallback would hang the job
-        try:
-            ex = DoneMaskExchange(block_rows, words, dev, kind="ipc", slots=max(2, slots), copy_engine=copy_engine)
-            ex.probe()
-            return ex, "ipc", None
-        except Exception as exc:
-            if kind == "ipc":
-                raise
-            note = "ipc unavailable (%s: %s): RCCL all-gather" % (type(exc).__name__, exc)
-    return DoneMaskExchange(block_rows, words, dev, kind="rccl"), "rccl", note
 
 
 # ------------------------------------------------------------------ main
@@ -462,18 +567,25 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from aquaticgymenv_amd.batched import BatchedAqua, LaunchEvents
-    from aquaticgymenv_amd.sharded import DoneMaskExchange
+    from aquaticgymenv_amd.sharded import Watchdog, open_exchange
 
     one_gpu = args.ranks_on_one_gpu
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL, mapped buffers): before the first HIP call
     dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     distributed = world > 1 or "RANK" in os.environ
+    # Everything from here to the end of the exchange's set-up can STALL rather than fail when a node is met for the first
+    # time (a rendezvous, an IPC mapping, a first copy over xGMI): the rendezvous has its own timeout, and a watchdog turns
+    # whatever else hangs into one stderr line + exit status 3 within --setup-deadline (cancelled once the set-up is done)
+    watchdog = Watchdog(args.rendezvous_timeout + args.setup_deadline, "rendezvous (init_process_group)") if distributed else None
     if distributed:
+        from datetime import timedelta
+        limit = timedelta(seconds=args.rendezvous_timeout)
         if one_gpu:
-            dist.init_process_group("gloo")              # RCCL refuses two ranks on one device; gloo carries the barriers
+            dist.init_process_group("gloo", timeout=limit)   # RCCL refuses two ranks on one device; gloo carries the barriers
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
+        watchdog.stage = "first collective (all_gather_object of the device names)"
     ranks_seen = dist.get_world_size() if distributed else 1
     if distributed:
         devices = [None] * ranks_seen
@@ -498,21 +610,36 @@ def main(argv=None):
     # 20-step region must not ship a 500-row buffer through RCCL)
     block_rows = max(chunk, min(GATHER_EVERY * CHUNK, args.steps))
     hist = [torch.zeros((block_rows, words), dtype=torch.int64, device=dev) for _ in range(2)]
-    exchange, exchange_kind, exchange_note = None, None, None
+    exchange, exchange_kind, exchange_note = None, None, args.exchange_note
     if world > 1 or args.force_exchange:
-        slots = max(exchange_blocks(args.warmup, chunk, block_rows), exchange_blocks(args.steps, chunk, block_rows), 1)
-        exchange, exchange_kind, exchange_note = make_exchange("ipc" if one_gpu else args.exchange, block_rows, words, dev, slots,
-                                                               rank, ranks_seen, torch, DoneMaskExchange, args.copy_engine)
+        slots = max([exchange_blocks(w, chunk, block_rows) for w in warmup_runs(args.warmup, args.steps)] +
+                    [exchange_blocks(args.steps, chunk, block_rows), 1])
+        if watchdog is not None:
+            watchdog.stage = "setting up the done-mask exchange (--exchange %s)" % args.exchange
+        # no failure and no stall of a transport ends the run: ipc -> rccl -> none, decided by all ranks together
+        # (sharded.open_exchange); with the ranks on one GPU there is no RCCL to fall back to (gloo carries the barriers)
+        exchange, exchange_kind, note = open_exchange(args.exchange, block_rows, words, dev, slots=slots,
+                                                      copy_engine=args.copy_engine, soft_deadline_s=args.soft_deadline,
+                                                      allow_rccl=not one_gpu)
+        exchange_note = "; ".join(n for n in (args.exchange_note, note) if n) or None
+    if watchdog is not None:
+        watchdog.cancel()
     runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk,
                         launch_events=LaunchEvents() if args.region_clock == "launch" else None)
     by_launch = runner.clocked_by_launch_events(args.steps)
     if args.region_clock == "launch" and not by_launch:
         raise SystemExit("--region-clock launch: a region of %d steps is more than one block of %d" % (args.steps, chunk))
-    runner.prepare(args.warmup)
+    warm = warmup_runs(args.warmup, args.steps)
+    for w in warm:
+        runner.prepare(w)
     if by_launch:
         runner.prepare_clocked(args.steps)
     else:
         runner.prepare(args.steps, timing=args.graph_node_events)
+    # region 0 must not be the first launch of its graphs (see warmup_runs)
+    uploaded = 0 if by_launch else runner.upload_unplayed(args.steps, warm)
+    first_replay = ("no graph" if (by_launch or not runner.use_graph) else
+                    "warm-up" if not uploaded else "hipGraphUpload (%d graph%s the warm-up does not replay)" % (uploaded, "s" * (uploaded != 1)))
 
     def drain():
         """everything this rank queued has run: the steps, and the done-mask gathers behind them on the side stream"""
@@ -531,7 +658,11 @@ def main(argv=None):
         if exchange is not None:
             exchange.note_fence()
 
-    runner.run(args.warmup)
+    for i, w in enumerate(warm):
+        if i:
+            rendezvous()                                 # (every run is a window of the exchange)
+        runner.run(w)
+        drain()
     drain()
     rendezvous()
     x_before = float(env.state[0, :n].double().sum().item())
@@ -571,8 +702,7 @@ def main(argv=None):
     if exchange is not None and segs:
         # the last block as it arrived: this rank's own copy must BE its done-mask buffer, and the other ranks' blocks must
         # show episodes ending there too (after the closing barrier every block of the region is in place everywhere)
-        last_slot = (exchange._slot - 1) % exchange.slots
-        got = exchange.gathered[last_slot]
+        got = exchange.gathered[exchange.last_slot()]
         peers = [int(popcount_words(got[r].cpu().numpy(), np)) for r in range(ranks_seen) if r != rank]
         exchange_check = {"own_block_intact": bool(torch.equal(got[rank], hist[segs[-1][0]])),
                           "episodes_in_peer_blocks": peers}
@@ -593,6 +723,12 @@ def main(argv=None):
         launch_s = statistics.median(launch_ev if by_launch else events) * 1e-3 / args.steps
         achieved = a_bytes * n / launch_s / 1e9
         traffic, traffic_src = committed_traffic(n, args)
+        # `value` counts every world of the batch in every step.  With next-step restarts a world that finished at tick t
+        # does not step during tick t + 1 (it is re-seeded and reports reward 0, term 0): those ticks are the episodes that
+        # ended one tick earlier -- counted here from the last region's own done masks (rank 0's shard)
+        restart_ticks = ended if (not args.no_auto_reset and args.reset_mode == 2) else 0
+        restart_frac = restart_ticks / float(max(args.steps * n, 1))
+        issue_us, issue_src = issue_bound(n, args, ended / float(max(args.steps, 1)))
         result = {
             "metric": "env-steps/sec at batch=262144; achieved HBM GB/s vs roofline; 1/2/4/8-GPU scaling",
             "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -607,7 +743,8 @@ def main(argv=None):
                           ("HIP graphs" if runner.use_graph else "eager launch loops"), chunk),
                        "baseline_config": "configs[3]" if args.continuous else ("configs[1]-like" if args.no_obstacles else "configs[2]"),
                        "worlds_per_gpu": n, "global_worlds": world * n, "parallelism": "range-partition x%d" % world,
-                       "launch": "eager" if by_launch else runner.launch, "done_mask_exchange": exchange is not None,
+                       "launch": "eager" if by_launch else runner.launch, "timed_graph_first_replay": first_replay,
+                       "done_mask_exchange": exchange is not None,
                        "done_mask_exchange_kind": exchange_kind, "done_mask_exchange_note": exchange_note,
                        "done_mask_copy_engine": args.copy_engine if exchange_kind == "ipc" else None,
                        "ranks_seen": ranks_seen, "devices": devices,
@@ -617,6 +754,7 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
+                         "issue_bound_us": issue_us, "issue_bound_source": issue_src,
                          "launch_us_regions": [e * 1e3 / args.steps for e in (launch_ev if by_launch else events)],
                          "launch_us_events": "launch" if by_launch else "stream",
                          "launch_us_stream_events_regions": [e * 1e3 / args.steps for e in events],
@@ -634,6 +772,7 @@ def main(argv=None):
                                   "boundaries included; the events are recorded on the launch stream around the region's "
                                   "graph launches.  Kernel-only duration: profiles/")},
             "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended,
+                       "restart_ticks_fraction": restart_frac, "live_world_steps_per_s": steps_per_s * (1.0 - restart_frac),
                        "done_mask_exchange_last_block": exchange_check},
         }
         if cpu is not None:
@@ -646,9 +785,15 @@ def main(argv=None):
         result_out.write(json.dumps(result) + "\n")
         result_out.flush()
     if exchange is not None:
-        exchange.stop()
+        exchange.close()                                 # collective: unmaps the peers' buffers behind a fence, ends the pump
     if distributed:
         dist.barrier()
+        from aquaticgymenv_amd import sharded
+        if sharded.ABANDONED_SETUP_THREADS:
+            # a set-up thread of this rank is still inside a call that never returned (the soft deadline left it behind): the
+            # line is out, every rank is past the barrier -- end here rather than tear the process groups down around it
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
     return result
 
@@ -685,6 +830,33 @@ def committed_traffic(n, args):
         return None, "committed PMC pass %s is of build %s, this is %s" % (row.get("source"), row.get("library_sha16"), tag)
     return (2.0 * row["FETCH_SIZE_per_launch_raw"] * 1024.0 + row["WRITE_SIZE_per_launch_raw"] * 1024.0,
             "%s (build %s)" % (row.get("source"), tag))
+
+
+SHADER_CLOCK_GHZ = 2.4       # measured on these kernels: profiles/r03/clock_probe.txt (2.38-2.43)
+SIMDS = 256 * 4              # MI355X: 256 compute units of four SIMDs (MI355X_MICROARCH.md)
+
+
+def issue_bound(n, args, restarts_per_step):
+    """(us per launch, source): the vector-issue floor of the benchmarked kernel from the committed instruction budget of
+    the SAME build (profiles/isa_budget.json, written by tools/r04/isa_budget.py from the compiler's own listing): VALU
+    issue cycles of a stepping wavefront x the wavefronts a SIMD steps + those of a re-seeding pass x the passes the
+    measured restarts need, / the shader clock.  A launch cannot be shorter than this however its memory traffic goes; the
+    HBM figure (`achieved`, `frac`) is the contract's, this is what actually bounds a 262 144-world launch."""
+    path = os.path.join(ROOT, "profiles", "isa_budget.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except Exception:
+        return None, "no profiles/isa_budget.json"
+    key = "ns_%s_%s" % ("f32x2" if args.continuous else "u8", "k0" if args.no_obstacles else "k8")
+    row = table.get(key)
+    if not row or args.no_auto_reset or args.reset_mode != 2:
+        return None, "no committed instruction budget for this configuration"
+    tag = library_tag()
+    if row.get("library_sha16") != tag:
+        return None, "committed budget is of build %s, this is %s" % (row.get("library_sha16"), tag)
+    cycles = (n / 64.0) * row["valu_cycles_stepping_wavefront"] + (restarts_per_step / 8.0) * row["valu_cycles_reseed_pass_per_world_group"]
+    return cycles / SIMDS / (SHADER_CLOCK_GHZ * 1e3), "%s (build %s)" % (row.get("source"), tag)
 
 
 def per_world_tables(torch, np, presets, BatchedAqua, n, dev):

@@ -35,11 +35,12 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 6   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
+#define AQUA_ABI_VERSION 7   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
                                 3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed;
                                 4: aqua_rollout_tables_fused_f32;
                                 5: aqua_ipc_*, aqua_copy_async (done-mask exchange by peer copies);
-                                6: aqua_rollout_events_f32 (events attached to the first / last launch) */
+                                6: aqua_rollout_events_f32 (events attached to the first / last launch);
+                                7: aqua_graph_upload */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
@@ -254,6 +255,9 @@ typedef struct AquaGraph AquaGraph;
 int aqua_graph_begin(void* stream);
 int aqua_graph_end(void* stream, AquaGraph** out);
 int aqua_graph_launch(AquaGraph* g, void* stream);
+/* hipGraphUpload: the executable graph's device-side resources are set up on `stream` now instead of inside its first
+ * launch (bench.py: a timed graph that the warm-up never replayed would otherwise pay for that inside region 0). */
+int aqua_graph_upload(AquaGraph* g, void* stream);
 int aqua_graph_destroy(AquaGraph* g);
 
 /*

@@ -20,9 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd, timeout=900):
+def _run(cmd, timeout=900, faults=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("AQUA_TEST_EXCHANGE_FAIL", None)
+    if faults:
+        env["AQUA_TEST_EXCHANGE_FAIL"] = faults            # honoured by aquaticgymenv_amd/sharded.py only
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, "rc %d\n--- stdout\n%s\n--- stderr\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -58,6 +61,12 @@ def _check_line(r, steps, warmup, n_gpus=1, envs=262144, timings_mean_something=
     assert "traffic" in roof and "traffic_source" in roof
     assert r["sanity"]["steps_queued"] == warmup + 5 * steps
     assert r["sanity"]["episodes_ended_last_region"] > 0
+    # what `value` counts: every world in every step; the restart ticks of the next-step mode are reported beside it
+    frac = r["sanity"]["restart_ticks_fraction"]
+    assert frac == pytest.approx(r["sanity"]["episodes_ended_last_region"] / float(steps * envs)) and 0.0 < frac < 0.1
+    assert r["sanity"]["live_world_steps_per_s"] == pytest.approx(r["value"] * (1.0 - frac))
+    assert r["config"]["timed_graph_first_replay"].startswith("hipGraphUpload" if warmup < steps else "warm-up") or clock == "launch"
+    assert "issue_bound_us" in roof and "issue_bound_source" in roof
 
 
 @pytest.mark.gpu
@@ -155,3 +164,58 @@ def test_ipc_done_mask_exchange_between_two_processes_on_one_gpu():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, "rc %d\n--- stdout\n%s\n--- stderr\n%s" % (p.returncode, p.stdout[-3000:], p.stderr[-3000:])
     assert "ipc exchange ok: 3 ranks" in p.stdout
+
+
+# ------------------------------------------------------------------ first contact cannot end without a line (round 4)
+_TWO_ON_ONE = [sys.executable, "bench.py", "--gpus", "2", "--ranks-on-one-gpu", "--envs", "65536", "--steps", "20", "--warmup", "5",
+               "--no-cpu-baseline"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("faults,soft,want", [
+    ("open", "45", "injected fault: hipIpcOpenMemHandle failed"),
+    ("probe", "45", "did not arrive intact"),
+    ("stall", "8", "still in stage 'injected fault: a set-up call that never returns' after 8 s"),
+])
+def test_a_transport_that_fails_or_stalls_does_not_take_the_line_with_it(faults, soft, want):
+    """two ranks on the one GPU, the IPC exchange made to fail at mapping, at the probe, or to STALL (a call that never
+    returns) on rank 1: both ranks drop it together inside their processes (no RCCL with two ranks on one device: the run
+    goes on without an exchange), the line arrives, and it says what happened"""
+    r = _run(_TWO_ON_ONE + ["--soft-deadline", soft], faults=faults)
+    _check_line(r, 20, 5, n_gpus=2, envs=65536, timings_mean_something=False)
+    cfg = r["config"]
+    assert cfg["done_mask_exchange"] is False and cfg["done_mask_exchange_kind"] is None
+    assert want in cfg["done_mask_exchange_note"] and "NO done-mask exchange in this run" in cfg["done_mask_exchange_note"]
+    assert r["sanity"]["done_mask_exchange_last_block"] is None
+
+
+@pytest.mark.gpu
+def test_ranks_that_hang_are_ended_and_replaced_by_fresh_ranks_without_the_exchange():
+    """the set-up of the FIRST set of ranks hangs where no soft deadline reaches (injected): their watchdog ends them with
+    status 3 inside --setup-deadline, bench.py's self-launch starts fresh ranks with --exchange none, and their line carries
+    the story"""
+    import time
+    t0 = time.time()
+    r = _run(_TWO_ON_ONE + ["--setup-deadline", "10", "--rendezvous-timeout", "20"], faults="hard-stall")
+    assert time.time() - t0 < 300
+    _check_line(r, 20, 5, n_gpus=2, envs=65536, timings_mean_something=False)
+    cfg = r["config"]
+    assert cfg["done_mask_exchange"] is False
+    assert "--exchange auto: ranks exited with status" in cfg["done_mask_exchange_note"]
+
+
+@pytest.mark.gpu
+def test_one_rank_under_the_launcher_falls_back_to_rccl_inside_the_process():
+    """under torch.distributed.run (what the driver uses for N > 1) nobody starts fresh ranks: an IPC transport that
+    fails is replaced by RCCL's all-gather inside the process, and by nothing when that fails too"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+           "--force-exchange"]
+    r = _run(cmd, faults="open")
+    _check_line(r, 20, 5)
+    assert r["config"]["done_mask_exchange_kind"] == "rccl" and "injected fault" in r["config"]["done_mask_exchange_note"]
+    assert r["sanity"]["done_mask_exchange_last_block"]["own_block_intact"] is True
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    r = _run(cmd, faults="open,rccl")
+    _check_line(r, 20, 5)
+    assert r["config"]["done_mask_exchange"] is False and "rccl unavailable" in r["config"]["done_mask_exchange_note"]

@@ -11,9 +11,15 @@ import bench
 class StubGraph(object):
     def __init__(self, env, steps, done_history, how="graph"):
         self.env, self.steps, self.done_history, self.how = env, steps, done_history, how
+        self.launches = self.uploads = 0
 
     def launch(self):
+        self.launches += 1
         self.env._do(self.steps, self.done_history, self.how)
+
+    def upload(self):
+        assert self.launches == 0, "an upload is for a graph that has not been launched yet"
+        self.uploads += 1
 
 
 class StubEnv(object):
@@ -179,8 +185,12 @@ def test_traffic_is_null_without_a_matching_build(monkeypatch):
 
 # ------------------------------------------------------------------ the N > 1 entry launches itself (round 2: `bench.py --gpus N` sys.exit()ed)
 class _Args(object):
-    def __init__(self, gpus, ranks_on_one_gpu=False):
+    def __init__(self, gpus, ranks_on_one_gpu=False, exchange="auto", exchange_note=None, launch_deadline=330.0):
         self.gpus, self.ranks_on_one_gpu = gpus, ranks_on_one_gpu
+        self.exchange, self.exchange_note, self.launch_deadline = exchange, exchange_note, launch_deadline
+
+
+LINE = '{"metric": "x"}\n'
 
 
 def test_self_launch_is_needed_only_for_a_bare_multi_gpu_command():
@@ -199,26 +209,126 @@ def test_launch_command_is_the_drivers_own():
 
 def test_self_launch_refuses_more_ranks_than_gpus(capsys):
     ran = []
-    rc = bench.self_launch(_Args(2), ["--gpus", "2"], device_count=1, run=lambda cmd, env: ran.append(cmd) or 0)
+    rc = bench.self_launch(_Args(2), ["--gpus", "2"], device_count=1, run=lambda cmd, env, deadline: ran.append(cmd) or (0, LINE, False))
     assert rc != 0 and not ran, "must fail before starting anything"
     assert "--gpus 2" in capsys.readouterr().err
-    assert bench.self_launch(_Args(2), ["--gpus", "2"], device_count=0, run=lambda cmd, env: 0) != 0
+    assert bench.self_launch(_Args(2), ["--gpus", "2"], device_count=0, run=lambda cmd, env, deadline: (0, LINE, False)) != 0
 
 
-def test_self_launch_starts_a_fresh_child_and_returns_its_status():
+def test_self_launch_starts_a_fresh_child_and_relays_its_line_and_status(capsys):
     seen = {}
 
-    def run(cmd, env):
-        seen["cmd"], seen["env"] = cmd, env
-        return 7
+    def run(cmd, env, deadline):
+        seen["cmd"], seen["env"], seen["deadline"] = cmd, env, deadline
+        return 7, LINE, False
     rc = bench.self_launch(_Args(2), ["--gpus", "2", "--steps", "3"], device_count=8, run=run)
-    assert rc == 7
+    assert rc == 7 and capsys.readouterr().out == LINE          # a line arrived: its ranks' status is the status
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
-    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["deadline"] == 330.0
     # the rehearsal layout is allowed on a 1-GPU box
     assert bench.self_launch(_Args(2, ranks_on_one_gpu=True), ["--gpus", "2", "--ranks-on-one-gpu"], device_count=1, run=run) == 7
+
+
+def test_fallback_chain_and_argument_rewriting():
+    assert bench.fallback_chain("auto", False) == ["auto", "rccl", "none"]
+    assert bench.fallback_chain("auto", True) == ["auto", "none"]          # ranks on one GPU: no RCCL to fall back to
+    for explicit in ("ipc", "rccl", "none"):
+        assert bench.fallback_chain(explicit, False) == [explicit]         # what was asked for, or a failure
+    assert bench.argv_with(["--gpus", "8", "--exchange", "auto", "--steps", "20"], "rccl", "why") == \
+        ["--gpus", "8", "--steps", "20", "--exchange", "rccl", "--exchange-note", "why"]
+    assert bench.argv_with(["--exchange=ipc", "--exchange-note=old", "--gpus", "2"], "none", None) == ["--gpus", "2", "--exchange", "none"]
+
+
+def test_self_launch_falls_back_to_fresh_ranks_until_a_line_arrives(capsys):
+    """--exchange auto: ranks that die, or hang past their deadline, are followed by FRESH ranks with --exchange rccl and
+    then --exchange none; the first line that arrives is relayed with its ranks' status, and the later attempts carry
+    what failed before them in --exchange-note"""
+    calls = []
+
+    def run(cmd, env, deadline):
+        calls.append((cmd, deadline))
+        n = len(calls)
+        if n == 1:
+            return 3, None, False                 # the watchdog's status, no line
+        if n == 2:
+            return -9, None, True                 # still running at its deadline: killed
+        return 0, LINE, False
+    rc = bench.self_launch(_Args(8), ["--gpus", "8", "--steps", "20", "--warmup", "5"], device_count=8, run=run)
+    out = capsys.readouterr()
+    assert rc == 0 and out.out == LINE and len(calls) == 3
+    first, second, third = (c for c, _ in calls)
+    assert "--exchange" not in first and first[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert second[second.index("--exchange") + 1] == "rccl" and third[third.index("--exchange") + 1] == "none"
+    note2, note3 = second[second.index("--exchange-note") + 1], third[third.index("--exchange-note") + 1]
+    assert "--exchange auto: ranks exited with status 3" in note2
+    assert note2 in note3 and "--exchange rccl: no line after 150 s" in note3
+    assert [d for _, d in calls] == [330.0, 150.0, 150.0]
+    assert "starting fresh ranks with --exchange rccl" in out.err and "--exchange none" in out.err
+    # every attempt failed: non-zero, nothing on stdout
+    calls.clear()
+    rc = bench.self_launch(_Args(8), ["--gpus", "8"], device_count=8, run=lambda cmd, env, deadline: (calls.append(cmd) or 1, None, False))
+    assert rc != 0 and len(calls) == 3 and capsys.readouterr().out == ""
+    # an explicit transport is not second-guessed
+    calls.clear()
+    rc = bench.self_launch(_Args(8, exchange="ipc"), ["--gpus", "8", "--exchange", "ipc"], device_count=8,
+                           run=lambda cmd, env, deadline: (calls.append(cmd) or 3, None, False))
+    assert rc == 3 and len(calls) == 1
+
+
+def test_run_ranks_relays_the_line_and_kills_what_outlives_its_deadline():
+    import io
+    import sys
+    import time
+    err = io.StringIO()
+    status, line, timed_out = bench.run_ranks([sys.executable, "-c", "print('chatter'); print('{\"a\": 1}'); print('more')"],
+                                              dict(__import__("os").environ), 30, err=err)
+    assert (status, line, timed_out) == (0, '{"a": 1}\n', False) and "chatter" in err.getvalue() and "more" in err.getvalue()
+    t0 = time.time()
+    status, line, timed_out = bench.run_ranks([sys.executable, "-c", "import time; time.sleep(600)"],
+                                              dict(__import__("os").environ), 1.0, err=err)
+    assert timed_out and line is None and status != 0 and time.time() - t0 < 30
+    status, line, timed_out = bench.run_ranks([sys.executable, "-c", "import sys; sys.exit(3)"], dict(__import__("os").environ), 30, err=err)
+    assert (status, line, timed_out) == (3, None, False)
+
+
+def test_warmup_replays_the_timed_graphs_or_uploads_them():
+    """region 0 must not be the first launch of its graphs: the warm-up budget is spent on whole timed regions where it is
+    large enough, and otherwise the timed graphs are uploaded ahead of time -- exactly `warmup` steps either way"""
+    assert bench.warmup_runs(5, 20) == [5] and bench.warmup_runs(0, 20) == [] and bench.warmup_runs(200, 2000) == [200]
+    assert bench.warmup_runs(20, 20) == [20] and bench.warmup_runs(100, 30) == [30, 30, 30, 10] and bench.warmup_runs(7, 1) == [1] * 7
+    for warmup, steps in ((5, 20), (200, 2000), (100, 30), (0, 1), (250, 230)):
+        assert sum(bench.warmup_runs(warmup, steps)) == warmup
+    # the driver's flags: the 20-step graph is not replayed by a 5-step warm-up -> uploaded
+    env, hist = StubEnv(), _hist(20)
+    r = bench.StepRunner(env, None, hist, None, use_graph=True, chunk=20)
+    warm = bench.warmup_runs(5, 20)
+    for w in warm:
+        r.prepare(w)
+    r.prepare(20)
+    assert r.upload_unplayed(20, warm) == 1 and r.graphs[(0, 0, 20)].uploads == 1 and r.graphs[(0, 0, 5)].uploads == 0
+    # defaults: 2 of the 2000-step region's 10 graphs are the warm-up's own
+    env, hist = StubEnv(), _hist()
+    r = bench.StepRunner(env, None, hist, None, use_graph=True, chunk=bench.CHUNK)
+    r.prepare(200)
+    r.prepare(2000)
+    assert r.upload_unplayed(2000, [200]) == 8
+    # warm-up >= steps: the timed graph itself is replayed, nothing to upload
+    env, hist = StubEnv(), _hist(30)
+    r = bench.StepRunner(env, None, hist, None, use_graph=True, chunk=30)
+    warm = bench.warmup_runs(100, 30)
+    for w in warm + [30]:
+        r.prepare(w)
+    assert r.upload_unplayed(30, warm) == 0
+    assert bench.StepRunner(StubEnv(), None, _hist(), None, use_graph=False, chunk=100).upload_unplayed(20, [5]) == 0
+
+
+def test_issue_bound_needs_a_budget_of_the_same_build(monkeypatch):
+    args = bench.parse([])
+    monkeypatch.setattr(bench, "library_tag", lambda: "0" * 16)
+    us, src = bench.issue_bound(262144, args, 5000.0)
+    assert us is None and isinstance(src, str) and src
 
 
 def test_exchange_blocks_counts_the_blocks_of_a_region():

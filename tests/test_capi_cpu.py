@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(capi):
     raw = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert capi.lib.aqua_version() == capi.ABI_VERSION == 6
+    assert capi.lib.aqua_version() == capi.ABI_VERSION == 7
     assert ctypes.sizeof(capi.AquaParams) == 32
 
 

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from aquaticgymenv_amd.sharded import DoneMaskExchange, shard_range, unpack_done_words
+from aquaticgymenv_amd.sharded import DoneMaskExchange, Watchdog, injected_faults, open_exchange, shard_range, unpack_done_words
 
 
 def test_shard_range_partitions_exactly():
@@ -141,8 +141,7 @@ def _bench_worker(rank, world, port, steps, warmup):
             # the block gathered last holds, for EVERY rank, the rows of the region's last block
             buf, row0, s, gathered = segs[-1]
             assert gathered
-            last_slot = (ex._slot - 1) % len(ex.gathered)
-            block = ex.gathered[last_slot]
+            block = ex.gathered[ex.last_slot()]
             first_row_tick = tick0 + steps - (row0 + s)          # tick of row 0 of that block
             for r in range(world):
                 want = r * 1000 + first_row_tick + torch.arange(1, row0 + s + 1, dtype=torch.int64)
@@ -216,3 +215,74 @@ def test_a_failure_on_one_rank_is_raised_on_every_rank(tmp_path):
     for rank in range(2):
         text = (tmp_path / ("agree%d.txt" % rank)).read_text()
         assert "the mapping failed on 1 of 2 ranks" in text and "rank 1: ValueError: cannot map rank 0" in text
+
+
+# ------------------------------------------------------------------ bounded time and fallbacks of the N > 1 set-up (round 4)
+def test_watchdog_names_the_stage_and_ends_the_process_unless_cancelled(capsys):
+    import time
+    fired = []
+    w = Watchdog(0.2, "mapping the peers' buffers", on_expire=fired.append)
+    w.stage = "probing"                                   # the stage can be moved along while the clock runs
+    time.sleep(0.6)
+    assert fired == [Watchdog.EXIT_STATUS] and Watchdog.EXIT_STATUS == 3
+    err = capsys.readouterr().err
+    assert "deadline of 0.2 s passed in stage 'probing'" in err and err.count("\n") == 1      # ONE line
+    fired.clear()
+    with Watchdog(0.2, "quick", on_expire=fired.append):
+        pass
+    time.sleep(0.5)
+    assert fired == []
+
+
+def test_fault_injection_is_off_unless_asked_for():
+    assert injected_faults({}) == set()
+    assert injected_faults({"AQUA_TEST_EXCHANGE_FAIL": "open, rccl"}) == {"open", "rccl"}
+    assert open_exchange("none", 4, 2, "cpu") == (None, None, None)
+    with pytest.raises(ValueError):
+        open_exchange("carrier pigeon", 4, 2, "cpu")
+
+
+def _fallback_worker(rank, world, port, tmpdir, faults, soft):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    if faults:
+        os.environ["AQUA_TEST_EXCHANGE_FAIL"] = faults
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        t0 = time.time()
+        ex, kind, note = open_exchange("auto", 3, 4, "cpu", slots=2, soft_deadline_s=soft)
+        took = time.time() - t0
+        outcome = "%s|%s|%.1f" % (kind, note, took)
+        if ex is not None:                    # the transport that was chosen works, on every rank, in step
+            local = torch.full((3, 4), rank + 1, dtype=torch.int64)
+            slot = ex.gather_async(local)
+            ex.fence()
+            assert [int(ex.gathered[slot][r, 0, 0]) for r in range(world)] == [1, 2]
+        dist.barrier()                        # the default group is untouched by whatever happened in the sandbox
+        with open(os.path.join(tmpdir, "out%d.txt" % rank), "w") as f:
+            f.write(outcome)
+    finally:
+        from aquaticgymenv_amd import sharded
+        if sharded.ABANDONED_SETUP_THREADS:
+            os._exit(0)                       # (what bench.py does: a thread of this process sits in a call that never returns)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("faults,soft,want_kind,want_note", [
+    ("", 20.0, "rccl", "ipc unavailable"),                            # no HIP device here: the IPC transport fails on every rank
+    ("rccl", 20.0, "None", "NO done-mask exchange in this run"),      # ... and so does the next one: the run goes on without
+    ("stall", 3.0, "rccl", "still in stage 'injected fault: a set-up call that never returns' after 3 s"),
+])
+def test_open_exchange_falls_back_together_on_every_rank(tmp_path, faults, soft, want_kind, want_note):
+    """two ranks (gloo, CPU): the IPC set-up fails (no GPU) or STALLS on one rank (injected) inside its sandbox; every rank
+    drops it together -- through the untouched default group -- and goes on with the collective transport (gloo stands in
+    for RCCL on CPU tensors), or with no exchange at all when that fails too"""
+    mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path), faults, soft), nprocs=2, join=True)
+    for rank in range(2):
+        kind, note, took = (tmp_path / ("out%d.txt" % rank)).read_text().split("|")
+        assert kind == want_kind and want_note in note, (rank, kind, note)
+        assert float(took) < soft + 15.0
+        if faults == "stall":
+            assert "rank 1: TimeoutError" in note                      # who stalled, where, is on the record
