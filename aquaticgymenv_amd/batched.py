@@ -66,10 +66,12 @@ class PreparedRollout(object):
         self._env, self.steps, self._args, self._tick_index = env, steps, list(args), tick_index
         self.reward, self.term = reward, term
         self._keep = keep                  # the tensors and events the marshalled pointers refer to
+        self._clip_view = None             # continuous thrusts [T][2][N] whose clipped worlds every launch() counts
 
     def launch(self):
         env = self._env
         self._args[self._tick_index] = env._tick
+        env._count_clipped(self._clip_view)            # the buffer as it is NOW: every launch steps with its current content
         _capi.check(_capi.lib.aqua_rollout_events_f32(*self._args), "aqua_rollout_events_f32")
         env._tick += self.steps
         return self.reward, self.term
@@ -85,10 +87,12 @@ class RolloutGraph(object):
         self.reward = reward
         self.term = term
         self._events = events             # (start, stop) AquaEvent handles recorded as nodes of the graph, or None
+        self._clip_view = None            # continuous thrusts [T][2][N] whose clipped worlds every launch() counts
 
     def launch(self):
         env = self._env
         env._sync_device_tick()
+        env._count_clipped(self._clip_view)            # (count_clipped=True: a replay steps with the buffer's CURRENT content)
         _capi.check(_capi.lib.aqua_graph_launch(self._handle, env._stream()), "aqua_graph_launch")
         env._tick += self.steps
         env._device_tick += self.steps
@@ -286,7 +290,7 @@ class BatchedAqua(object):
 
     def _count_clipped(self, thrusts):
         """thrusts float32 [..., 2, n]: adds the worlds with a thrust outside [0.2, 0.5] (aqua.py:145-150) to the counter"""
-        if self.clipped_actions is not None:
+        if self.clipped_actions is not None and thrusts is not None:
             out = (thrusts < 0.2) | (thrusts > 0.5)
             self.clipped_actions += out.any(dim=-2).sum()
 
@@ -368,7 +372,14 @@ class BatchedAqua(object):
         del keep
         return self.obs, self.reward[:n], self.term[:n]
 
-    def _rollout_args(self, steps, actions, soa_ld):
+    def _clip_view(self, steps, actions):
+        """the thrusts a rollout of `steps` steps reads from `actions`, when there is a clipped-action counter to feed"""
+        if self.clipped_actions is None or actions is None or isinstance(actions, str):
+            return None
+        return actions[:steps, :, :self.num_envs]
+
+    def _rollout_args(self, steps, actions, soa_ld, count=True):
+        """count=False: the caller (a captured graph, a prepared rollout) counts clipped actions at every launch() instead"""
         torch = self.torch
         n = self.num_envs
         if actions is None or isinstance(actions, str):
@@ -377,7 +388,8 @@ class BatchedAqua(object):
             if actions.dtype != torch.float32 or actions.dim() != 3 or actions.shape[0] < steps or actions.shape[1] != 2 \
                     or actions.shape[2] < n or actions.stride(2) != 1:
                 raise ValueError("continuous rollout actions must be float32 [T][2][>=N]")
-            self._count_clipped(actions[:steps, :, :n])
+            if count:
+                self._count_clipped(actions[:steps, :, :n])
             return actions.data_ptr(), _capi.ACT_F32X2, actions.stride(1), actions.stride(0)
         kinds = {torch.uint8: _capi.ACT_U8, torch.int32: _capi.ACT_I32, torch.int64: _capi.ACT_I64}
         if actions.dtype not in kinds or actions.dim() != 2 or actions.shape[0] < steps or actions.shape[1] < n \
@@ -452,7 +464,7 @@ class BatchedAqua(object):
         is a single C call (one launch per step, one obstacle table for the batch; queued on the stream current NOW)."""
         if self.per_world:
             raise ValueError("prepare_rollout(): batches with one obstacle table")
-        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld)
+        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld, count=False)
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         ev0, ev1 = (events.start, events.stop) if isinstance(events, LaunchEvents) else (events or (None, None))
@@ -462,7 +474,9 @@ class BatchedAqua(object):
                 self.ld, self.time.data_ptr(), steps, aptr, kind, ald, astride, self.seed, self._tick, None,
                 reward.data_ptr(), term.data_ptr(), ostride, done.data_ptr(), dstride, self._norm_ptr(),
                 int(self.auto_reset), 0, ev0, ev1, stream]
-        return PreparedRollout(self, steps, args, 14, reward, term, (actions, done, events, reward, term))
+        p = PreparedRollout(self, steps, args, 14, reward, term, (actions, done, events, reward, term))
+        p._clip_view = self._clip_view(steps, actions)
+        return p
 
     def _rollout_tables(self, steps, aptr, kind, ald, astride, tick, tick_base, reward, term, ostride, done, dstride, advance, s):
         return _capi.lib.aqua_rollout_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),
@@ -484,7 +498,7 @@ class BatchedAqua(object):
         kernels add a device-resident tick base that the graph's last node advances by `steps`.
         timing=True: the graph starts and ends with an event-record node (RolloutGraph.elapsed_ms())."""
         torch = self.torch
-        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld)
+        aptr, kind, ald, astride = self._rollout_args(steps, actions, self.ld, count=False)     # (nothing steps at capture time)
         reward, term, ostride = self._rollout_out(steps, keep_all)
         done, dstride = self._done_out(steps, done_history)
         lib = _capi.lib
@@ -551,6 +565,7 @@ class BatchedAqua(object):
             _capi.check(rc_end, "aqua_graph_end")
         g = RolloutGraph(self, handle, steps, reward, term, events)
         g._actions = actions          # keep the action buffer alive as long as the graph
+        g._clip_view = self._clip_view(steps, actions)
         g.done_history = done if dstride else None
         return g
 
@@ -574,6 +589,8 @@ class BatchedAqua(object):
             d["obstacle_tables"] = np.array(self.obstacle_tables, copy=True)
         if self.obs_norm_buf is not None:
             d["obs_norm"] = self.obs_norm_buf.cpu().clone()
+        if self.clipped_actions is not None:
+            d["clipped_actions"] = int(self.clipped_actions)
         return d
 
     def load_state_dict(self, d):
@@ -599,6 +616,8 @@ class BatchedAqua(object):
             dst.copy_(src)
         if self.obs_norm_buf is not None and "obs_norm" in d:
             self.obs_norm_buf.copy_(d["obs_norm"])
+        if self.clipped_actions is not None and "clipped_actions" in d:
+            self.clipped_actions.fill_(int(d["clipped_actions"]))
         self._tick, self._resets = int(d["tick"]), int(d["resets"])
         self._device_tick = -1            # graphs captured on this batch read the tick base from the device: refresh it
         return self

@@ -113,11 +113,12 @@ constexpr int64_t NS_LAUNCH_MAX_WORLDS = int64_t(1) << 28;
 
 __device__ __forceinline__ int args_waves(const StepArgs& a) { return a.waves; }
 __device__ __forceinline__ int args_waves(const NsArgs& a) { return static_cast<int>(a.flags & NS_WAVES_MASK); }
+__device__ __forceinline__ int args_random_boat(const StepArgs& a) { return a.random_boat; }
+__device__ __forceinline__ int args_random_boat(const NsArgs& a) { return (a.flags & NS_RANDOM_BOAT) != 0; }
+__device__ __forceinline__ int args_random_goal(const StepArgs& a) { return a.random_goal; }
+__device__ __forceinline__ int args_random_goal(const NsArgs& a) { return (a.flags & NS_RANDOM_GOAL) != 0; }
 
-// ------------------------------------------------------------------ vector load/store helpers
-// `p` is a wave-uniform row pointer already advanced to the tile, `off` the lane's element offset
-// inside the tile (32-bit), `rem` the number of valid elements from p on.  FULL tiles carry no guards:
-// the loads of a lane are issued back to back as global_load_dword{,x2,x4} v, voffset, s[base].
+// ------------------------------------------------------------------ load/store helpers
 // Stores carry agent scope (`global_store ... sc1`): they are written through the XCD's L2 while the kernel runs, so the
 // end-of-kernel release has almost nothing left to write back (-0.3 us per launch; system scope: the same; non-temporal:
 // -0.1; hinted loads: slower -- profiles/LOG.md).
@@ -177,31 +178,6 @@ template <typename T>
 __device__ __forceinline__ void st_at(T* base, uint32_t byte_off, T v, bool wb = false)
 {
     st1(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v, wb);
-}
-
-template <int VEC, bool FULL, typename T>
-__device__ __forceinline__ void load_row(const T* __restrict__ p, uint32_t off, int64_t rem, T (&v)[VEC])
-{
-    static_assert(VEC == 1, "one world per lane");
-    if constexpr (FULL) {
-        v[0] = ld1(p + off);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = (static_cast<int64_t>(off) + j < rem) ? p[off + j] : T(0);
-    }
-}
-
-template <int VEC, bool FULL, typename T>
-__device__ __forceinline__ void store_row(T* __restrict__ p, uint32_t off, int64_t rem, const T (&v)[VEC], bool wb = false)
-{
-    static_assert(VEC == 1, "one world per lane");
-    if constexpr (FULL) {
-        st1(p + off, v[0], wb);
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            if (static_cast<int64_t>(off) + j < rem) st1(p + off + j, v[j], wb);
-    }
 }
 
 // rows are read with scalar loads from the constant address space (they follow the 32-byte header)
@@ -294,13 +270,6 @@ __device__ __forceinline__ ExactMotion exact_motion(const Motion& m)
 __device__ __forceinline__ int sample_discrete(uint32_t r) { return static_cast<int>((static_cast<uint64_t>(r >> 8) * 3u) >> 24); }
 __device__ __forceinline__ float sample_thrust(uint32_t r) { return fmaf(0.3f, u_01(r), 0.2f); }
 
-// ------------------------------------------------------------------ one launch per step
-// Workgroup = TILE_WORLDS lanes, tile = TILE_WORLDS consecutive worlds, one per lane.  Worlds that finish are
-// not re-seeded by their own lane (that would be 1-2 active lanes per wavefront, in every wavefront,
-// looping over rejection attempts): their tile-local indices are appended to a list in LDS and, after
-// one barrier, groups of RESET_GROUP lanes re-seed them densely (reset_env_group) and write the fresh
-// state straight to HBM; the owning lane then skips its state store for that world.  One workgroup
-// per tile (no grid-stride loop: nothing loop-invariant to hoist, which keeps the SGPR file unspilled).
 // Diagnostic build only (-DAQUA_STAMPS=1, tools/stamps.py): s_memtime stamps per wavefront at phase
 // boundaries, written to a buffer no product code reads.  Never defined in the shipped library.
 #ifndef AQUA_STAMPS
@@ -347,11 +316,6 @@ template <typename A> __device__ __forceinline__ uint64_t launch_tick(const A& a
 #define AQUA_RTSTAMP(slot) do { } while (0)
 #endif
 
-struct TileShared {
-    uint32_t count;
-    uint16_t list[TILE_WORLDS];
-};
-
 // Philox draws of the lane's worlds (pairs share a call: see STREAM_STEP in aqua_device.hpp)
 template <int VEC, bool SCALAR_KEY = true>
 __device__ __forceinline__ void pair_draws(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream,
@@ -385,81 +349,6 @@ __device__ __forceinline__ void write_norm(const StepArgs& a, int64_t i, float x
     st1(o + 4 * a.ld, gy * 0.01f, wb);
 }
 
-// the same rows written as uniform row base + the lane's 32-bit byte offset (st_at)
-__device__ __forceinline__ void write_norm_at(const StepArgs& a, int64_t tile, uint32_t byte_off, float x, float y, float th,
-                                              float gx, float gy, bool wb = false)
-{
-    if (a.obs_norm == nullptr) return;
-    float* const o = a.obs_norm + tile;
-    st_at(o + 0 * a.ld, byte_off, x * 0.01f, wb);
-    st_at(o + 1 * a.ld, byte_off, y * 0.01f, wb);
-    st_at(o + 2 * a.ld, byte_off, fmaf(th, 0.15915494309189535f, 0.5f), wb);
-    st_at(o + 3 * a.ld, byte_off, gx * 0.01f, wb);
-    st_at(o + 4 * a.ld, byte_off, gy * 0.01f, wb);
-}
-
-// reward / term / packed done bits of one wavefront's worlds
-template <int VEC>
-__device__ __forceinline__ void store_outputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, bool full,
-                                              const float (&rew)[VEC], const uint8_t (&code)[VEC], uint32_t done_mask,
-                                              bool wb = false)
-{
-    const int lane = threadIdx.x & 63;
-    if (full) {
-        store_row<VEC, true>(a.reward + tile, off, rem, rew, wb);
-        store_row<VEC, true>(a.term + tile, off, rem, code, wb);
-    } else {
-        store_row<VEC, false>(a.reward + tile, off, rem, rew, wb);
-        store_row<VEC, false>(a.term + tile, off, rem, code, wb);
-    }
-    static_assert(VEC == 1, "one world per lane: the wavefront's ballot IS its done word");
-    if (a.done_bits != nullptr) {
-        const uint64_t b = __ballot(done_mask & 1u);
-        const int64_t word = (tile + static_cast<int64_t>(threadIdx.x & ~63u)) / 64;
-        if (lane == 0 && word < ((a.N + 63) >> 6)) store_done_word(a.done_bits + word, b, a.N);
-    }
-}
-
-// Issues every load of a lane's worlds and consumes NOTHING: the time row first (the restart bookkeeping
-// waits for it alone, vmcnt counts in order), the action as loaded (fold_actions() clamps it later).
-template <int VEC, int AK, bool FULL>
-__device__ __forceinline__ void load_inputs(const StepArgs& a, int64_t tile, uint32_t off, int64_t rem, float (&x)[VEC],
-                                            float (&y)[VEC], float (&th)[VEC], float (&gx)[VEC], float (&gy)[VEC],
-                                            float (&wx)[VEC], float (&wy)[VEC], int32_t (&t)[VEC], int64_t (&araw)[VEC],
-                                            float (&avl)[VEC], float (&avr)[VEC], float (&u0)[VEC], float (&u1)[VEC])
-{
-    const int64_t ld = a.ld;
-    const float* const row0 = a.state + tile;
-    load_row<VEC, FULL>(a.time + tile, off, rem, t);
-    load_row<VEC, FULL>(row0 + 0 * ld, off, rem, x);
-    load_row<VEC, FULL>(row0 + 1 * ld, off, rem, y);
-    load_row<VEC, FULL>(row0 + 2 * ld, off, rem, th);
-    load_row<VEC, FULL>(row0 + 3 * ld, off, rem, gx);
-    load_row<VEC, FULL>(row0 + 4 * ld, off, rem, gy);
-    load_row<VEC, FULL>(row0 + 5 * ld, off, rem, wx);
-    load_row<VEC, FULL>(row0 + 6 * ld, off, rem, wy);
-    if constexpr (AK == AQUA_ACT_U8) {
-        uint8_t v[VEC];
-        load_row<VEC, FULL>(static_cast<const uint8_t*>(a.action) + tile, off, rem, v);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) araw[j] = v[j];
-    } else if constexpr (AK == AQUA_ACT_I32) {
-        int32_t v[VEC];
-        load_row<VEC, FULL>(static_cast<const int32_t*>(a.action) + tile, off, rem, v);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) araw[j] = v[j];
-    } else if constexpr (AK == AQUA_ACT_I64) {
-        load_row<VEC, FULL>(static_cast<const int64_t*>(a.action) + tile, off, rem, araw);
-    } else if constexpr (AK == AQUA_ACT_F32X2) {
-        load_row<VEC, FULL>(static_cast<const float*>(a.action) + tile, off, rem, avl);
-        load_row<VEC, FULL>(static_cast<const float*>(a.action) + a.action_ld + tile, off, rem, avr);
-    }
-    if (a.noise != nullptr) {
-        load_row<VEC, FULL>(a.noise + tile, off, rem, u0);
-        load_row<VEC, FULL>(a.noise + a.noise_ld + tile, off, rem, u1);
-    }
-}
-
 // Scheduling fence between the Philox draws and the first use of anything loaded: the draws (~280 cycles,
 // no memory operand) then always run in the shadow of the loads instead of after a wait for them.
 template <int VEC, int AK>
@@ -490,169 +379,6 @@ __device__ __forceinline__ void fold_actions(const int64_t (&araw)[VEC], int (&a
         if constexpr (AK == AQUA_ACT_U8) aidx[j] = araw[j] > 2 ? 2 : static_cast<int>(araw[j]);
         else if constexpr (AK == AQUA_ACT_I32 || AK == AQUA_ACT_I64) aidx[j] = fold_index(araw[j]);
     }
-}
-
-// SMALL: the table has a quick table (at most QUICK_MAX rows; decided on the host like step_ns_kernel's
-// SMALL_TABLE): the obstacle look and the re-seeding read it, and nothing walks the rows outside the rare paths.
-// RESTART == false: the launch never restarts a world (auto_reset 0, the reference's own step()): no list, no
-// barrier, no re-seeding code in the kernel.  RESTART == true serves both (the run-time a.auto_reset decides).
-template <int AK, bool SMALL, bool RESTART, bool WB = false>
-__device__ __forceinline__ void step_tile(const StepArgs& a, const StepConst& k, uint64_t tick, int64_t tile,
-                                          TileShared& sh)
-{
-    // One world per lane.  Two and four worlds per lane (16-byte row accesses) were built and measured at every batch
-    // size up to 16.7 M worlds and never won (262 144: 20 vs 37 us in round 1; 16.7 M without restarts: 177 / 183 /
-    // 184 us for 1 / 2 / 4, profiles/r02/ab_16m_vec.txt): the helpers below keep their width parameter, the kernels no
-    // longer have one.
-    constexpr int VEC = 1;
-    constexpr int QUICK = SMALL ? QUICK_ALWAYS : QUICK_NEVER;
-    constexpr int BLOCK = TILE_WORLDS / VEC;
-    const int64_t ld = a.ld;
-    const int64_t rem = a.N - tile;                      // > 0, uniform
-    const uint32_t off = threadIdx.x * VEC;
-    const int lane = threadIdx.x & 63;
-    float* const row0 = a.state + tile;                  // uniform row pointers (SGPR pairs)
-    int32_t* const trow = a.time + tile;
-
-    float x[VEC], y[VEC], th[VEC], gx[VEC], gy[VEC], wx[VEC], wy[VEC], u0[VEC], u1[VEC], avl[VEC], avr[VEC];
-    int32_t t[VEC];
-    int aidx[VEC];
-    int64_t araw[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) { aidx[j] = 2; araw[j] = 2; avl[j] = 0.5f; avr[j] = 0.5f; u0[j] = 0.0f; u1[j] = 0.0f; }
-    const bool full = rem >= TILE_WORLDS;                // uniform: a whole tile carries no per-lane guards
-    AQUA_RTSTAMP(0);
-    if (full) load_inputs<VEC, AK, true>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, araw, avl, avr, u0, u1);
-    else load_inputs<VEC, AK, false>(a, tile, off, rem, x, y, th, gx, gy, wx, wy, t, araw, avl, avr, u0, u1);
-
-    const uint64_t env0 = static_cast<uint64_t>(a.env_offset + tile) + off;
-    if (a.noise == nullptr) {
-        uint32_t w0[VEC], w1[VEC];
-        pair_draws<VEC>(a.seed, env0, tick, STREAM_STEP, w0, w1);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { u0[j] = u_pm1(w0[j]); u1[j] = u_pm1(w1[j]); }
-    }
-    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
-        uint32_t w0[VEC], w1[VEC];
-        pair_draws<VEC, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[j] = sample_discrete(w0[j]);
-            else { avl[j] = sample_thrust(w0[j]); avr[j] = sample_thrust(w1[j]); }
-        }
-    }
-    hold_loads<VEC, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
-    fold_actions<VEC, AK>(araw, aidx);
-
-    if constexpr (AK == AQUA_ACT_BEARING) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) aidx[j] = bearing_action(x[j], y[j], th[j], gx[j], gy[j]);
-    }
-    AQUA_STAMP(1);          // Philox done (loads may still be in flight)
-    float rew[VEC];
-    uint8_t code[VEC];
-    Motion mo[VEC];
-    float x0[VEC], y0[VEC], th0[VEC], wx0[VEC], wy0[VEC];      // step inputs, kept for the exact path
-    uint32_t knife_mask = 0, done_mask = 0;
-    asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        x0[j] = x[j]; y0[j] = y[j]; th0[j] = th[j]; wx0[j] = wx[j]; wy0[j] = wy[j];
-        EnvState e{x[j], y[j], th[j], gx[j], gy[j], wx[j], wy[j], t[j]};
-        mo[j] = decode_motion<AK>(k, aidx[j], avl[j], avr[j]);
-        uint32_t c;
-        const bool knife = fast_step<false, QUICK>(e, mo[j].h, mo[j].w, mo[j].chord, u0[j], u1[j], k, rew[j], c);
-        const bool valid = static_cast<int64_t>(off) + j < rem;
-        knife_mask |= (knife && valid) ? (1u << j) : 0u;
-        code[j] = static_cast<uint8_t>(c);
-        x[j] = e.x; y[j] = e.y; th[j] = e.th; wx[j] = e.wx; wy[j] = e.wy; t[j] = e.t;
-    }
-    AQUA_STAMP(2);          // fast path done
-    // knife-edge worlds: redo pose, reward and termination in float64 (reference operation order)
-    if (any_lane(knife_mask != 0)) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (knife_mask & (1u << j)) {
-                const ExactOut o = exact_step(x0[j], y0[j], th0[j], gx[j], gy[j], wx0[j], wy0[j], t[j],
-                                              exact_motion<AK>(mo[j]), k.K, k.obst64, k.obst, k.band2, k.time_limit);
-                x[j] = o.x; y[j] = o.y; th[j] = o.th; rew[j] = o.reward; code[j] = static_cast<uint8_t>(o.term);
-            }
-        }
-    }
-    AQUA_STAMP(3);          // exact path (if any) done
-#pragma unroll
-    for (int j = 0; j < VEC; ++j)
-        done_mask |= (code[j] != 0 && static_cast<int64_t>(off) + j < rem) ? (1u << j) : 0u;
-    constexpr bool wb = WB;                              // the stores of this tile: left to the L2's write-back, or written through
-    store_outputs<VEC>(a, tile, off, rem, full, rew, code, done_mask, wb);
-
-    // Worlds that finished go on the workgroup's list and are re-seeded densely after one barrier.
-    // worlds whose fresh state is written by a re-seeding group (their own lane skips its state stores)
-    const uint32_t skip_mask = (RESTART && a.auto_reset) ? done_mask : 0u;
-    constexpr uint32_t own_reset_mask = 0;
-    if (RESTART && a.auto_reset) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (done_mask & (1u << j)) sh.list[atomicAdd(&sh.count, 1u)] = static_cast<uint16_t>(off + j);
-        }
-        AQUA_STAMP(4);      // outputs stored, list appended
-    }
-    // The lane's own state stores go out AHEAD of the barrier (behind the list append, which the barrier waits for):
-    // nothing behind it needs them, and the wavefronts that re-seed end with the restart stores only.
-    if (skip_mask == 0 && own_reset_mask == 0 && full) {
-        store_row<VEC, true>(row0 + 0 * ld, off, rem, x, wb);
-        store_row<VEC, true>(row0 + 1 * ld, off, rem, y, wb);
-        store_row<VEC, true>(row0 + 2 * ld, off, rem, th, wb);
-        store_row<VEC, true>(row0 + 5 * ld, off, rem, wx, wb);
-        store_row<VEC, true>(row0 + 6 * ld, off, rem, wy, wb);
-        store_row<VEC, true>(trow, off, rem, t, wb);
-        if (a.obs_norm != nullptr) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) write_norm(a, tile + off + j, x[j], y[j], th[j], gx[j], gy[j], wb);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const uint32_t i = off + j;
-            if (!(skip_mask & (1u << j)) && static_cast<int64_t>(i) < rem) {
-                st1(row0 + 0 * ld + i, x[j], wb); st1(row0 + 1 * ld + i, y[j], wb); st1(row0 + 2 * ld + i, th[j], wb);
-                st1(row0 + 5 * ld + i, wx[j], wb); st1(row0 + 6 * ld + i, wy[j], wb);
-                st1(trow + i, t[j], wb);
-                write_norm(a, tile + i, x[j], y[j], th[j], gx[j], gy[j], wb);
-            }
-        }
-    }
-    if (RESTART && a.auto_reset) {
-        uint32_t* const cnt = &sh.count;
-        uint16_t* const list = sh.list;
-        __syncthreads();
-        AQUA_STAMP(5);      // barrier passed
-        const uint32_t n_done = *cnt;
-        constexpr uint32_t GROUPS = BLOCK / RESET_GROUP;
-        const uint32_t wave_first_group = (threadIdx.x & ~63u) / RESET_GROUP;
-        for (uint32_t qb = wave_first_group; qb < n_done; qb += GROUPS) {
-            const uint32_t q = qb + (lane / RESET_GROUP);
-            const bool active = q < n_done;
-            const uint32_t i = list[active ? q : 0];
-            const uint64_t world = static_cast<uint64_t>(a.env_offset + tile) + i;
-            EnvState e;
-            if constexpr (QUICK == QUICK_ALWAYS)
-                e = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
-                                                            k.K, k.obst, nullptr, k.quick, k.Kc);
-            else
-                e = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
-            if (active && (lane & (RESET_GROUP - 1)) == 0) {
-                st1(row0 + 0 * ld + i, e.x, wb); st1(row0 + 1 * ld + i, e.y, wb); st1(row0 + 2 * ld + i, e.th, wb);
-                st1(row0 + 3 * ld + i, e.gx, wb); st1(row0 + 4 * ld + i, e.gy, wb);
-                st1(row0 + 5 * ld + i, e.wx, wb); st1(row0 + 6 * ld + i, e.wy, wb);
-                st1(trow + i, e.t, wb);
-                write_norm(a, tile + i, e.x, e.y, e.th, e.gx, e.gy, wb);
-            }
-        }
-    }
-    AQUA_STAMP(6);          // group re-seeding done
-
-    AQUA_RTSTAMP(7);        // state stores issued (wall clock)
 }
 
 // tick of this launch.  The device-resident base is written only by tick_kernel, between launches, so it
@@ -706,18 +432,6 @@ __device__ __forceinline__ void tick_housekeeping()
     }
 }
 
-template <int AK, bool SMALL, bool RESTART, bool WB = false>
-__global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const StepArgs a)
-{
-    __shared__ TileShared sh;
-    tick_housekeeping();
-    if (RESTART && threadIdx.x == 0) sh.count = 0;
-    const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
-    if (RESTART && a.auto_reset) __syncthreads();
-    const uint64_t tick = launch_tick(a);
-    step_tile<AK, SMALL, RESTART, WB>(a, k, tick, static_cast<int64_t>(blockIdx.x) * TILE_WORLDS, sh);
-}
-
 // ------------------------------------------------------------------ one launch per step, next-step restart
 // auto_reset == 2 ("next-step", the Gymnasium >= 1.0 convention): a world that finishes at tick t keeps its
 // terminal state, is marked pending (negative time) and is restarted DURING tick t + 1, when it does not step:
@@ -747,6 +461,16 @@ constexpr int NS_MAIN_WAVES = 4;
 constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = NS_TILE;
 constexpr int NS_SCAN_ROWS = 4, NS_SCAN = NS_SCAN_ROWS * NS_BLOCK;      // worlds per re-seeding block
 constexpr int NS_RESEED_GROUP = 8;
+// Late loads.  A launch that is ONE round of blocks has two phases -- every wavefront waits for its nine rows (1.6 us of
+// fabric traffic), then every wavefront computes -- and neither overlaps the other.  Three wavefronts of four therefore
+// issue their loads BEHIND their Philox draws instead of ahead of them: their requests reach the memory system a few
+// hundred nanoseconds later, and the arithmetic of the first wavefronts runs while those are served.  Per step at 262 144
+// worlds (profiles/r04/stagger/): 4.89 -> 4.71 us; half of the wavefronts 4.74, one of four 4.82, all of them 4.84; any
+// s_sleep in front of the late loads loses (4.98-5.28).
+#ifndef AQUA_NS_LATE_LOADS
+#define AQUA_NS_LATE_LOADS 1
+#endif
+constexpr bool NS_LATE_LOADS = AQUA_NS_LATE_LOADS != 0;
 static_assert(NS_SCAN <= 65536, "list entries are 16-bit offsets");
 static_assert(NS_SCAN % NS_TILE == 0, "a re-seeding block covers whole stepping tiles");
 // batches of at least this many worlds interleave the two roles through the grid.  Measured per step, interleaved vs
@@ -935,45 +659,25 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     int64_t araw[1] = {2};
     int aidx[1] = {2};
     const uint32_t o4 = o * 4u;                         // byte offset inside a float / int row
-#ifndef AQUA_NS_STAGGER
-#define AQUA_NS_STAGGER 0
+#ifndef AQUA_NS_LATE_INTERLEAVE
+#define AQUA_NS_LATE_INTERLEAVE 0
 #endif
-    // (experiment, profiles/r04/stagger/: half of the stepping wavefronts issue their loads BEHIND their draws, so that
-    // the launch's memory phase and its arithmetic phase overlap between the two halves)
-    bool late = false;
-#if AQUA_NS_STAGGER == 1 || AQUA_NS_STAGGER == 4
-    late = (role_index & 1u) != 0;
-#elif AQUA_NS_STAGGER == 2
-    late = (threadIdx.x & 64u) != 0;
-#elif AQUA_NS_STAGGER == 3
-    late = (role_index & 2u) != 0;
-#elif AQUA_NS_STAGGER >= 5
-#ifndef AQUA_NS_SLEEP
-#define AQUA_NS_SLEEP 6
-#endif
-    const uint32_t wv = uni(threadIdx.x) >> 6;
-    const uint32_t cls = AQUA_NS_STAGGER == 5 ? ((role_index + wv) & 3u) : (AQUA_NS_STAGGER == 6 ? (role_index & 3u) : wv);
-    late = cls != 0;
-#endif
+    // late loads (NS_LATE_LOADS above): wavefronts 1-3 of the block issue theirs behind the draws
+    const bool late = NS_LATE_LOADS && (!INTERLEAVE || AQUA_NS_LATE_INTERLEAVE) && (threadIdx.x >> 6) != 0u;
     const auto issue_loads = [&]() {
-    tin[0] = ld_at(a.time, o4);
-    x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
-    gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
-    wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
-    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
-    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
-    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
-    else if constexpr (AK == AQUA_ACT_F32X2) {
-        avl[0] = ld_at(static_cast<const float*>(a.action), o4);
-        avr[0] = ld_at(a.action_hi, o4);
-    }
+        tin[0] = ld_at(a.time, o4);
+        x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
+        gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
+        wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
+        if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
+        else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
+        else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
+        else if constexpr (AK == AQUA_ACT_F32X2) {
+            avl[0] = ld_at(static_cast<const float*>(a.action), o4);
+            avr[0] = ld_at(a.action_hi, o4);
+        }
     };
-#if AQUA_NS_STAGGER == 4
-    if (late) __builtin_amdgcn_s_sleep(12);
-    issue_loads();
-#else
     if (!late) issue_loads();
-#endif
     constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;     // tables of up to 8 rows: the quick table (5.22 -> 5.08 us)
     const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick = launch_tick(a);
@@ -995,14 +699,8 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
         if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
         else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
     }
-#if AQUA_NS_STAGGER >= 1 && AQUA_NS_STAGGER != 4
     asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));
-#if AQUA_NS_STAGGER >= 5
-    if (cls == 2) __builtin_amdgcn_s_sleep(AQUA_NS_SLEEP);
-    if (cls == 3) __builtin_amdgcn_s_sleep(2 * AQUA_NS_SLEEP);
-#endif
     if (late) issue_loads();
-#endif
     asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));   // scheduling fence, see hold_loads()
     hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
     AQUA_RTSTAMP(4);        // draws done, loads back
@@ -1103,13 +801,19 @@ __device__ __forceinline__ ReseedTicket publish_reseed(bool need, RolloutShared&
 }
 
 // the duty wavefront re-seeds the published worlds (tick: the tick whose draws the restart uses)
-template <bool SMALL>
-__device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepArgs& a, const StepConst& k, uint64_t tick,
+template <bool SMALL, typename A>
+__device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const A& a, const StepConst& k, uint64_t tick,
                                              int64_t block_first_world, RolloutShared& sh, int parity)
 {
     constexpr int WAVES = BLOCK_SMALL / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef AQUA_DUTY_BY_TICK_ONLY              // (timing experiment: round 3's choice)
     if (tk.n == 0 || wave != static_cast<int>(tick & (WAVES - 1))) return;
+#else
+    // (a different wavefront every tick AND for every block: wavefront i of every block of a CU runs on SIMD i, and a duty
+    // that depended on the tick alone put the re-seeding passes of all of a CU's blocks on one SIMD)
+    if (tk.n == 0 || wave != static_cast<int>((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1))) return;
+#endif
     uint32_t first[WAVES + 1];
     first[0] = 0;
 #pragma unroll
@@ -1125,10 +829,10 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const StepA
         const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
         EnvState f;
         if constexpr (SMALL)
-            f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal,
+            f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, args_random_boat(a), args_random_goal(a),
                                                         k.K, k.obst, nullptr, k.quick, k.Kc);
         else
-            f = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, a.random_boat, a.random_goal, k.K, k.obst);
+            f = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, args_random_boat(a), args_random_goal(a), k.K, k.obst);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             float* r = sh.result[q];
             r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
@@ -1143,6 +847,345 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
     if (need) {
         const float* r = sh.result[tk.slot];
         e.x = r[0]; e.y = r[1]; e.th = r[2]; e.gx = r[3]; e.gy = r[4]; e.wx = r[5]; e.wy = r[6]; e.t = 0;
+    }
+}
+
+// ------------------------------------------------------------------ one launch per step: no restart, or restart in the same launch
+// Workgroup = TILE_WORLDS lanes, tile = TILE_WORLDS consecutive worlds, one per lane; the per-lane path is the stepping
+// role of step_ns_kernel without the restart markers (same arguments: NsArgs, same addressing, the same late loads).
+// RESTART == false (auto_reset 0, the reference's own step(), which never restarts a world): no list, no barrier, no
+// re-seeding code in the kernel.  RESTART == true (auto_reset 1): worlds that finish are not re-seeded by their own lane
+// (that would be 1-2 active lanes per wavefront, in every wavefront, looping over rejection attempts): their tile-local
+// indices go on a list in LDS (one private segment per wavefront: ballot + prefix count) and, after ONE barrier, groups of
+// RESET_GROUP lanes re-seed them densely (reset_env_group, draws of this tick) and write the fresh state straight to
+// HBM; the owning lane skips its state stores for that world.  Tiles of 1024 worlds: 512 / 256 are slower here (6.46 /
+// 6.66 / 7.00 us per step, profiles/r03/ab_tile_worlds.txt), and so is the in-tile hand-off of step_tile_kernel at this
+// batch size (7.5 us: profiles/r04/same_step_tile/) -- a launch that is one round of blocks wants the lanes' own stores
+// out ahead of the barrier and the re-seeding from scalar operands.
+struct TileShared {
+    uint32_t count[TILE_WORLDS / 64];
+    uint16_t list[TILE_WORLDS / 64][64];
+};
+
+template <int AK, bool SMALL_TABLE, bool RESTART, bool WB = false>
+__global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
+{
+    tick_housekeeping<NsArgs>();
+    const uint32_t tile = blockIdx.x * TILE_WORLDS;
+    const uint32_t rem = a.N - tile;                   // >= 1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t last = (rem < TILE_WORLDS ? rem : static_cast<uint32_t>(TILE_WORLDS)) - 1u;
+    const uint32_t off = threadIdx.x;
+    const bool valid = off < rem;
+    const uint32_t o = tile + (off < last ? off : last);
+    float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
+    int32_t tin[1];
+    int64_t araw[1] = {2};
+    int aidx[1] = {2};
+    const uint32_t o4 = o * 4u;
+    const bool late = NS_LATE_LOADS && (wave & 3) != 0;          // see step_ns_kernel
+    const auto issue_loads = [&]() {
+        tin[0] = ld_at(a.time, o4);
+        x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
+        gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
+        wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
+        if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
+        else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
+        else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
+        else if constexpr (AK == AQUA_ACT_F32X2) {
+            avl[0] = ld_at(static_cast<const float*>(a.action), o4);
+            avr[0] = ld_at(a.action_hi, o4);
+        }
+    };
+    if (!late) issue_loads();
+    constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;
+    const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
+    const uint64_t tick = launch_tick(a);
+    const uint64_t env0 = (static_cast<uint64_t>(a.env_offset) + tile) + off;
+    if (__builtin_expect(!(a.flags & NS_HAS_NOISE), 1)) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
+        u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
+    } else {
+        u0[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise)), o4);
+        u1[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise) + sizeof(float*)), o4);
+        asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));
+    }
+    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
+        if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
+        else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
+    }
+    asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));
+    if (late) issue_loads();
+    asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));   // scheduling fence, see hold_loads()
+    hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
+    fold_actions<1, AK>(araw, aidx);
+    if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
+    const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
+    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], tin[0]};
+    const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
+    float rew;
+    uint32_t code;
+    asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));                   // the table's lines are resident from here on
+    const bool knife = fast_step<false, QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && valid;
+    if (__builtin_expect(any_lane(knife), 0)) {
+        if (knife) {
+            const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
+                                           k.obst, k.band2, k.time_limit);
+            e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
+        }
+    }
+    const bool done = valid && code != 0u;
+    uint32_t s4 = o4, s1 = o;                           // the stores' own copies of the lane offset (see step_ns_kernel)
+    asm volatile("" : "+v"(s4), "+v"(s1));
+    constexpr bool wb = WB;
+    if (valid) {
+        st_at(a.reward, s4, rew, wb);
+        st_at(a.term, s1, static_cast<uint8_t>(code), wb);
+    }
+    const uint64_t done_ballot = __ballot(done);
+    if (a.done_bits != nullptr) {
+        const uint32_t word = (tile >> 6) + (uni(off) >> 6);
+        if (word < ((a.N + 63u) >> 6) && lane == 0) {
+            if (a.flags & NS_DONE_WORD_WB) a.done_bits[word] = done_ballot;
+            else st1(a.done_bits + word, done_ballot);
+        }
+    }
+    // The lane's own state stores go out AHEAD of the barrier: nothing behind it needs them, and the wavefronts that
+    // re-seed end with the restart stores only.  A finished world's fresh state is written by its group below.
+    if (valid && !(RESTART && done)) {
+        st_at(a.row[0], s4, e.x, wb); st_at(a.row[1], s4, e.y, wb); st_at(a.row[2], s4, e.th, wb);
+        st_at(a.row[5], s4, e.wx, wb); st_at(a.row[6], s4, e.wy, wb);
+        st_at(a.time, s4, e.t, wb);
+        ns_write_norm(a, s4, e.x, e.y, e.th, gx[0], gy[0], wb);
+    }
+    if constexpr (RESTART) {
+        __shared__ TileShared sh;
+        constexpr int WAVES = TILE_WORLDS / 64;
+        if (done) sh.list[wave][__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done_ballot >> 32),
+                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(done_ballot), 0u))] = static_cast<uint16_t>(off);
+        if (lane == 0) sh.count[wave] = static_cast<uint32_t>(__builtin_popcountll(done_ballot));
+        __syncthreads();
+        uint32_t first[WAVES + 1];
+        first[0] = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.count[w];
+        const uint32_t n_done = uni(first[WAVES]);
+        const int waves = args_waves(a), random_boat = args_random_boat(a), random_goal = args_random_goal(a);
+        const uint64_t env_base = static_cast<uint64_t>(a.env_offset) + tile;
+        constexpr uint32_t GROUPS = TILE_WORLDS / RESET_GROUP;
+        for (uint32_t qb = static_cast<uint32_t>(wave) * (64 / RESET_GROUP); qb < n_done; qb += GROUPS) {
+            const uint32_t q = qb + (lane / RESET_GROUP);
+            const bool active = q < n_done;
+            uint32_t seg = 0;
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+            const uint32_t i = sh.list[seg][active ? q - first[seg] : 0];
+            EnvState f;
+            if constexpr (SMALL_TABLE)
+                f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, env_base + i, tick, waves, random_boat, random_goal,
+                                                            k.K, k.obst, nullptr, k.quick, k.Kc);
+            else
+                f = reset_env_group<RESET_GROUP>(active, a.seed, env_base + i, tick, waves, random_boat, random_goal, k.K, k.obst);
+            if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                const uint32_t i4 = (tile + i) * 4u;
+                st_at(a.row[0], i4, f.x, wb); st_at(a.row[1], i4, f.y, wb); st_at(a.row[2], i4, f.th, wb);
+                st_at(a.row[3], i4, f.gx, wb); st_at(a.row[4], i4, f.gy, wb);
+                st_at(a.row[5], i4, f.wx, wb); st_at(a.row[6], i4, f.wy, wb);
+                st_at(a.time, i4, f.t, wb);
+                ns_write_norm(a, i4, f.x, f.y, f.th, f.gx, f.gy, wb);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ one launch per step, next-step restart, batches of millions
+// step_ns_kernel splits the launch by role so that nothing of a restart is on the path of a launch that is a few
+// microseconds long; the price is eight scattered 4-byte stores per restarted world (every one a 32-byte sector on its
+// way to HBM: writes 1.16x the algorithmic bytes at 16.7 M worlds) and blocks that only scan and re-seed.  In a batch of
+// millions of worlds a block's own latency no longer matters -- the next block of the grid fills the gap -- and the
+// traffic does.  step_tile_kernel keeps the restart INSIDE the 256-world tile, with the fused rollout's protocol: the lanes of
+// the worlds to restart publish themselves on an LDS list (one barrier), ONE wavefront of the block (a different one
+// every tick) re-seeds them eight lanes per world while the others step their worlds, the owners pick the fresh states up
+// behind a second barrier and store them with the tile's coalesced row stores (the goal rows, which no stepping lane
+// writes, as a masked store of their own: two sectors per restart instead of eight).  No re-seeding blocks, no second
+// read of the time row.  Markers, draws and results are step_ns_kernel's bit for bit (Philox is keyed by world and tick).
+struct NsTileShared {
+    RolloutShared r;
+    ObstF rows[NS_TABLE_ROWS > 0 ? NS_TABLE_ROWS : 1];       // small tables: the re-seeding pass reads them from here
+};
+
+// the duty wavefront of a tile re-seeds the worlds on the tile's list (publish_reseed) and leaves the fresh states in LDS.
+// Which wavefront: a different one every tick AND for every block -- wavefront i of every block of a CU runs on SIMD i,
+// so a duty that depended on the tick alone would put the re-seeding passes of all of a CU's blocks on one SIMD.
+template <bool SMALL_TABLE>
+__device__ __forceinline__ void serve_tile(const ReseedTicket& tk, const NsArgs& a, uint64_t tick, uint32_t tile, NsTileShared& sh)
+{
+    constexpr int WAVES = NS_MAIN_WAVES;
+    const int lane = threadIdx.x & 63;
+    if (tk.n == 0 || (threadIdx.x >> 6) != ((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1))) return;
+    uint32_t first[WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.r.count[0][w];
+    const int waves = args_waves(a), random_boat = args_random_boat(a), random_goal = args_random_goal(a);
+    const uint64_t env_base = static_cast<uint64_t>(a.env_offset) + tile;
+    constexpr uint32_t PER_PASS = 64 / NS_RESEED_GROUP;
+    for (uint32_t qb = 0; qb < tk.n; qb += PER_PASS) {
+        const uint32_t q = qb + (lane / NS_RESEED_GROUP);
+        const bool active = q < tk.n;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+        const uint32_t owner = sh.r.list[0][seg][active ? q - first[seg] : 0];
+        EnvState f;
+        if constexpr (SMALL_TABLE)
+            f = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env_base + owner, tick, waves, random_boat, random_goal,
+                                                                a.K, obstacle_rows(a.obst_blob), sh.rows);
+        else
+            f = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env_base + owner, tick, waves, random_boat, random_goal, a.K,
+                                                 obstacle_rows(a.obst_blob));
+        if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
+            float* r = sh.r.result[q];
+            r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
+        }
+    }
+}
+
+// MODE: AQUA_RESET_NEXT_STEP (batches of millions, above) or AQUA_RESET_SAME_STEP: the worlds that finish in this launch
+// are re-seeded in it (draws of this tick) -- the same protocol behind the step instead of beside it: the list by
+// ballots instead of atomics, a barrier of four wavefronts instead of sixteen, and the fresh states stored by their own
+// lanes with the tile's row stores instead of eight scattered words (step_kernel's same-step form: 6.3 us per step at
+// 262 144 worlds, of which list + barrier 0.86, scattered stores 0.45; profiles/r03/ab_same_step.txt).
+template <int AK, bool SMALL_TABLE, bool WB, int MODE>
+__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void step_tile_kernel(const NsArgs a)
+{
+    static_assert(MODE == AQUA_RESET_NEXT_STEP || MODE == AQUA_RESET_SAME_STEP, "a restart mode");
+    constexpr bool NEXT = MODE == AQUA_RESET_NEXT_STEP;
+    __shared__ NsTileShared sh;
+    tick_housekeeping<NsArgs>();
+    const uint32_t tile = blockIdx.x * NS_TILE;
+    const uint32_t rem = a.N - tile;                   // >= 1
+    const int lane = threadIdx.x & 63;
+    const uint32_t last = (rem < NS_TILE ? rem : static_cast<uint32_t>(NS_TILE)) - 1u;
+    const uint32_t off = threadIdx.x;
+    const bool valid = off < rem;
+    const uint32_t o = tile + (off < last ? off : last);
+    float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
+    int32_t tin[1];
+    int64_t araw[1] = {2};
+    int aidx[1] = {2};
+    const uint32_t o4 = o * 4u;
+    tin[0] = ld_at(a.time, o4);
+    x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
+    gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
+    wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
+    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
+    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
+    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
+    else if constexpr (AK == AQUA_ACT_F32X2) {
+        avl[0] = ld_at(static_cast<const float*>(a.action), o4);
+        avr[0] = ld_at(a.action_hi, o4);
+    }
+    // small tables go to LDS for the re-seeding pass, as in step_ns_kernel's re-seeding blocks (one vector load per lane,
+    // in flight with the state; the quick table's SGPR operands are the stepping path's)
+    uint32_t table_word = 0;
+    if (SMALL_TABLE && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
+        table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
+    const uint64_t tick = launch_tick(a);
+    int32_t t0 = tin[0];
+    bool restart = false, pending = false;
+    ReseedTicket tk{0u, 0u};
+    if constexpr (NEXT) {
+        asm volatile("" : "+v"(tin[0]));
+        // the markers of step_ns_kernel: restarted last tick -> steps from 0; finished last tick -> restarts now; any
+        // other marker waits
+        t0 = tin[0] == restart_code(tick - 1) ? 0 : tin[0];
+        restart = valid && tin[0] == done_code(tick - 1);
+        pending = valid && t0 < 0;
+    }
+    if (SMALL_TABLE && threadIdx.x < NS_TABLE_ROWS * 8) {
+        const bool present = threadIdx.x < static_cast<uint32_t>(a.K) * 8;
+        reinterpret_cast<uint32_t*>(sh.rows)[threadIdx.x] = present ? table_word : ((threadIdx.x & 7u) == 4u ? 0xFF61B1E6u : 0u);
+    }
+    if constexpr (NEXT) {
+        tk = publish_reseed(restart, sh.r, 0);          // (one barrier: the list and the table are in place)
+        serve_tile<SMALL_TABLE>(tk, a, tick, tile, sh);  // the duty wavefront; the others go straight on
+    }
+    // ---- every wavefront steps its worlds
+    constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;
+    const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
+    const uint64_t env0 = (static_cast<uint64_t>(a.env_offset) + tile) + off;
+    if (__builtin_expect(!(a.flags & NS_HAS_NOISE), 1)) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
+        u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
+    } else {
+        u0[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise)), o4);
+        u1[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise) + sizeof(float*)), o4);
+    }
+    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
+        uint32_t w0[1], w1[1];
+        pair_draws<1, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
+        if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
+        else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
+    }
+    if constexpr (!NEXT) asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));      // the draws run in the loads' shadow
+    hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
+    fold_actions<1, AK>(araw, aidx);
+    if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
+    const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
+    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], NEXT ? t0 : tin[0]};
+    const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
+    float rew;
+    uint32_t code;
+    const bool live = valid && !pending;
+    asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));
+    const bool knife = fast_step<false, QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
+    if (__builtin_expect(any_lane(knife), 0)) {
+        if (knife) {
+            const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
+                                           k.obst, k.band2, k.time_limit);
+            e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
+        }
+    }
+    if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
+    const bool done = code != 0u;
+    constexpr bool wb = WB;
+    if (valid) {
+        st_at(a.reward, o4, rew, wb);
+        st_at(a.term, o, static_cast<uint8_t>(code), wb);
+    }
+    if (a.done_bits != nullptr) {
+        const uint64_t b = __ballot(done);
+        const uint32_t word = (tile >> 6) + (uni(off) >> 6);
+        if (word < ((a.N + 63u) >> 6) && lane == 0) {
+            if (a.flags & NS_DONE_WORD_WB) a.done_bits[word] = b;
+            else st1(a.done_bits + word, b);
+        }
+    }
+    int32_t t_out = (NEXT && done) ? done_code(tick) : e.t;
+    if constexpr (!NEXT) {
+        restart = done;                                 // (done implies valid)
+        tk = publish_reseed(restart, sh.r, 0);
+        serve_tile<SMALL_TABLE>(tk, a, tick, tile, sh);
+    }
+    if (tk.n != 0) {                                    // block-uniform
+        __syncthreads();
+        if (restart) {
+            const float* r = sh.r.result[tk.slot];
+            e.x = r[0]; e.y = r[1]; e.th = r[2]; e.gx = r[3]; e.gy = r[4]; e.wx = r[5]; e.wy = r[6];
+            t_out = NEXT ? restart_code(tick) : 0;
+            st_at(a.row[3], o4, e.gx, wb); st_at(a.row[4], o4, e.gy, wb);      // the only rows a stepping lane never writes
+        }
+    }
+    if (live || restart) {                              // the tile's row stores, whole lines wherever no lane waits
+        st_at(a.row[0], o4, e.x, wb); st_at(a.row[1], o4, e.y, wb); st_at(a.row[2], o4, e.th, wb);
+        st_at(a.row[5], o4, e.wx, wb); st_at(a.row[6], o4, e.wy, wb);
+        st_at(a.time, o4, t_out, wb);
+        ns_write_norm(a, o4, e.x, e.y, e.th, e.gx, e.gy, wb);
     }
 }
 
@@ -1253,6 +1296,21 @@ struct ResetShared {
 struct TablesShared {
     uint32_t count[BLOCK_SMALL / 64];
     uint8_t list[BLOCK_SMALL / 64][64];
+};
+// per-world tables of any length: the rows of a world that is being re-seeded, fetched once by the eight lanes of its group
+// together (reset_env_group<.., RESEED_COOP>): one slot of 5 K floats per group of every wavefront of the block, in
+// DYNAMIC shared memory -- sized by the launch for the table's length (coop_bytes(): 11 KB at 17 rows, 41 KB at 64), so
+// that short tables keep their blocks per CU
+#ifndef AQUA_TABLES_RESEED
+#define AQUA_TABLES_RESEED RESEED_COOP      // (RESEED_WORLD: round 3's form, the rows fetched two at a time inside the attempt loop)
+#endif
+extern __shared__ float coop_rows[];
+struct CoopSlots {
+    int K;
+    __device__ __forceinline__ const ObstF* slot() const
+    {
+        return reinterpret_cast<const ObstF*>(coop_rows + (threadIdx.x / RESET_GROUP) * (5 * K));
+    }
 };
 // Hand-off of a restarting world's table rows from its own lane (which loaded them with its state) to the eight lanes
 // that re-seed it: HANDOFF_PER_WAVE slots per wavefront and round (1.2 worlds of a wavefront restart in a step; a wavefront
@@ -1430,6 +1488,7 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     } else if constexpr (RESTART) {
         // tables of more than eight rows: the groups read their world's rows from memory
         __shared__ TablesShared sh;
+        const CoopSlots coop{a.K};
         constexpr int WAVES = BLOCK_SMALL / 64;
         const int wave = threadIdx.x >> 6;
         if (done) sh.list[wave][__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done_ballot >> 32),
@@ -1450,9 +1509,9 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32 + tile, nullptr, tld, i};
-            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
+            const EnvState f = reset_env_group<RESET_GROUP, AQUA_TABLES_RESEED>(
                 active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
-                nullptr, nullptr, nullptr, 0, &own);
+                nullptr, coop.slot(), nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
                 st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
                 st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
@@ -1489,6 +1548,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
                                                                   float band2, float band2_tight)
 {
     __shared__ ResetShared sh;
+    const CoopSlots coop{a.K};
     tick_housekeeping();
     bool reseed_role;
     uint32_t role;
@@ -1549,9 +1609,9 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
         const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
         const int64_t i = base + local;
         const WorldTable own{t32 + base, nullptr, tld, local};
-        const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
+        const EnvState f = reset_env_group<RESET_GROUP, AQUA_TABLES_RESEED>(
             active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
-            nullptr, nullptr, 0, &own);
+            coop.slot(), nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             st1(a.state + 0 * ld + i, f.x); st1(a.state + 1 * ld + i, f.y); st1(a.state + 2 * ld + i, f.th);
             st1(a.state + 3 * ld + i, f.gx); st1(a.state + 4 * ld + i, f.gy);
@@ -1592,7 +1652,12 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
     // table and every sixth world restarting per step a single server was the whole step (126 us per step; the
     // one-launch-per-step kernels 113).
     constexpr int WORLD_WAVES = WPB / 64, SERVERS = WPB == BLOCK_SMALL ? 1 : WAVES - WORLD_WAVES;
+#ifdef AQUA_DUTY_BY_TICK_ONLY
     const int server = WPB == BLOCK_SMALL ? (wave == static_cast<int>(tick & (WAVES - 1)) ? 0 : -1) : wave - WORLD_WAVES;
+#else
+    const int server = WPB == BLOCK_SMALL ? (wave == static_cast<int>((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1)) ? 0 : -1)
+                                          : wave - WORLD_WAVES;
+#endif
     if (tk.n == 0 || server < 0) return;
     uint32_t first[WAVES + 1];
     first[0] = 0;
@@ -1773,6 +1838,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
                                                                    const float* __restrict__ t32, int64_t tld)
 {
     __shared__ ResetShared sh;
+    const CoopSlots coop{a.K};
     constexpr int WAVES = BLOCK_SMALL / 64;
     const uint64_t tick = launch_tick(a);
     const int64_t base = static_cast<int64_t>(blockIdx.x) * RESET_SCAN, ld = a.ld, rem = a.N - base;   // rem > 0
@@ -1827,8 +1893,8 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
         const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
         const int64_t i = base + local;
         const WorldTable wt{t32 + base, nullptr, tld, local};
-        const EnvState e = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
-                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
+        const EnvState e = reset_env_group<RESET_GROUP, AQUA_TABLES_RESEED>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
+                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, coop.slot(),
                                                                       nullptr, 0, &wt);
         if (active && (lane & (RESET_GROUP - 1)) == 0) store(i, e);
     }
@@ -2007,37 +2073,62 @@ void launch_kernel(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, const La
     else hipExtLaunchKernelGGL(kernel, grid, block, 0, s, ev.start, ev.stop, 0, args...);
 }
 
-hipError_t launch_step(const StepArgs& a, int kind, hipStream_t s, const LaunchEvents& ev = {})
+void fill_ns_args(NsArgs& a, const StepArgs& a0, int kind, int64_t first, int64_t n, bool housekeeping_head, bool housekeeping_tail);
+
+// same-step restart: batches of at least this many worlds restart inside 256-world tiles with the hand-off of
+// step_tile_kernel (whole-line stores) instead of step_kernel's 1024-world tiles
+#ifndef AQUA_SS_TILE_MIN
+#define AQUA_SS_TILE_MIN INT64_MAX
+#endif
+constexpr int64_t SAME_STEP_TILE_MIN = AQUA_SS_TILE_MIN;
+
+// auto_reset 0 / 1: step_kernel (or, same-step restart of a large batch, step_tile_kernel), one launch per
+// NS_LAUNCH_MAX_WORLDS worlds
+hipError_t launch_step(const StepArgs& a0, int kind, hipStream_t s, const LaunchEvents& ev = {})
 {
-    if ((a.N + TILE_WORLDS - 1) / TILE_WORLDS > MAX_GRID) return hipErrorInvalidValue;
-    const dim3 grid(grid_for(a.N, TILE_WORLDS, MAX_GRID)), block(TILE_WORLDS);
-    const bool small = a.K > 0 && a.K <= QUICK_MAX;
-    const bool plain = a.auto_reset == 0;               // no restart: no list, no barrier, no re-seeding code in the kernel
-    const bool wb = !plain && a.N >= STORE_WB_SAME_STEP_MIN;
-#define AQUA_STEP_LAUNCH(AK)                                                                                     \
-    case AK:                                                                                                     \
-        if (plain && small) launch_kernel((step_kernel<AK, true, false>), grid, block, s, ev, a);            \
-        else if (plain) launch_kernel((step_kernel<AK, false, false>), grid, block, s, ev, a);               \
-        else if (small && wb) launch_kernel((step_kernel<AK, true, true, true>), grid, block, s, ev, a);     \
-        else if (wb) launch_kernel((step_kernel<AK, false, true, true>), grid, block, s, ev, a);             \
-        else if (small) launch_kernel((step_kernel<AK, true, true>), grid, block, s, ev, a);                 \
-        else launch_kernel((step_kernel<AK, false, true>), grid, block, s, ev, a);                           \
+    const bool plain = a0.auto_reset == 0;              // no restart: no list, no barrier, no re-seeding code in the kernel
+    const bool wb = !plain && a0.N >= STORE_WB_SAME_STEP_MIN;
+    const bool in_tile = !plain && a0.N >= SAME_STEP_TILE_MIN;
+    const bool small = NS_TABLE_ROWS > 0 && a0.K <= NS_TABLE_ROWS;
+    for (int64_t first = 0; first < a0.N; first += NS_LAUNCH_MAX_WORLDS) {
+        const int64_t n = a0.N - first < NS_LAUNCH_MAX_WORLDS ? a0.N - first : NS_LAUNCH_MAX_WORLDS;
+        const bool head = first == 0, tail = first + n == a0.N;
+        LaunchEvents e;
+        if (head) e.start = ev.start;
+        if (tail) e.stop = ev.stop;
+        NsArgs a;
+        fill_ns_args(a, a0, kind, first, n, head, tail);
+        const int worlds_per_block = in_tile ? NS_TILE : TILE_WORLDS;
+        const dim3 grid(static_cast<unsigned>((n + worlds_per_block - 1) / worlds_per_block)), block(worlds_per_block);
+#define AQUA_STEP_LAUNCH(AK)                                                                                                     \
+    case AK:                                                                                                                     \
+        if (plain && small) launch_kernel((step_kernel<AK, true, false>), grid, block, s, e, a);                                 \
+        else if (plain) launch_kernel((step_kernel<AK, false, false>), grid, block, s, e, a);                                    \
+        else if (in_tile && small && wb) launch_kernel((step_tile_kernel<AK, true, true, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);   \
+        else if (in_tile && small) launch_kernel((step_tile_kernel<AK, true, false, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);        \
+        else if (in_tile && wb) launch_kernel((step_tile_kernel<AK, false, true, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);           \
+        else if (in_tile) launch_kernel((step_tile_kernel<AK, false, false, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);                \
+        else if (small && wb) launch_kernel((step_kernel<AK, true, true, true>), grid, block, s, e, a);                          \
+        else if (wb) launch_kernel((step_kernel<AK, false, true, true>), grid, block, s, e, a);                                  \
+        else if (small) launch_kernel((step_kernel<AK, true, true>), grid, block, s, e, a);                                      \
+        else launch_kernel((step_kernel<AK, false, true>), grid, block, s, e, a);                                                \
         break;
-    switch (kind) {
-        AQUA_STEP_LAUNCH(AQUA_ACT_U8)
-        AQUA_DEV_OTHER_KINDS(AQUA_STEP_LAUNCH)
-        default: return hipErrorInvalidValue;
-    }
+        switch (kind) {
+            AQUA_STEP_LAUNCH(AQUA_ACT_U8)
+            AQUA_DEV_OTHER_KINDS(AQUA_STEP_LAUNCH)
+            default: return hipErrorInvalidValue;
+        }
 #undef AQUA_STEP_LAUNCH
-    return hipGetLastError();
+        const hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
 }
 
-// One next-step launch over worlds [first, first + n) of the caller's batch (n <= NS_LAUNCH_MAX_WORLDS, first a multiple of
-// NS_SCAN): StepArgs -> the kernel's own NsArgs, pointers advanced to the range.
-hipError_t launch_step_ns_range(const StepArgs& a0, int kind, int64_t first, int64_t n, bool interleave, bool wb, bool housekeeping_head,
-                                bool housekeeping_tail, hipStream_t s, const LaunchEvents& ev)
+// StepArgs -> the NsArgs of ONE launch over worlds [first, first + n) of the caller's batch (n <= NS_LAUNCH_MAX_WORLDS,
+// first a multiple of NS_SCAN): pointers advanced to the range
+void fill_ns_args(NsArgs& a, const StepArgs& a0, int kind, int64_t first, int64_t n, bool housekeeping_head, bool housekeeping_tail)
 {
-    NsArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int r = 0; r < 7; ++r) a.row[r] = a0.state + r * a0.ld + first;
     a.time = a0.time + first;
@@ -2058,6 +2149,13 @@ hipError_t launch_step_ns_range(const StepArgs& a0, int kind, int64_t first, int
     if (a0.N > DONE_WORD_WRITE_THROUGH_MAX_WORLDS) a.flags |= NS_DONE_WORD_WB;       // (store_done_word(): by the BATCH's size)
     if (housekeeping_head) a.tick_copy_to = a0.tick_copy_to;         // see tick_housekeeping(): block 0 of ONE launch per step
     if (housekeeping_tail) { a.tick_bump_to = a0.tick_bump_to; a.tick_bump = a0.tick_bump; }
+}
+
+hipError_t launch_step_ns_range(const StepArgs& a0, int kind, int64_t first, int64_t n, bool interleave, bool wb, bool housekeeping_head,
+                                bool housekeeping_tail, hipStream_t s, const LaunchEvents& ev)
+{
+    NsArgs a;
+    fill_ns_args(a, a0, kind, first, n, housekeeping_head, housekeeping_tail);
     const int64_t tiles = interleave ? (static_cast<int64_t>(a.reseed_blocks) + 7) / 8 * 8 * (NS_SCAN / NS_TILE + 1)
                                      : (n + NS_TILE - 1) / NS_TILE + a.reseed_blocks;
     const dim3 grid(static_cast<unsigned>(tiles)), block(NS_BLOCK);
@@ -2418,6 +2516,8 @@ int fill_table_args(StepArgs& a, const AquaParams* p, const float* tab32, int K,
 }  // namespace
 
 namespace {
+size_t coop_bytes(int K) { return static_cast<size_t>(BLOCK_SMALL / RESET_GROUP) * 5u * static_cast<size_t>(K) * sizeof(float); }
+
 struct TableArgs {
     const float* t32;
     const double* t64;
@@ -2447,7 +2547,9 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     }
     if (blocks > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
-#define AQUA_TAB_ARGS grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight
+    // the kernels whose re-seeding groups fetch their world's rows together (tables that are not held in registers)
+    const size_t coop = (!regs && a.auto_reset != 0) ? coop_bytes(a.K) : 0;
+#define AQUA_TAB_ARGS grid, block, coop, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight
 #define AQUA_TAB_LAUNCH(AK)                                                                                        \
     case AK:                                                                                                        \
         if (ns_tile && wide) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
@@ -2606,7 +2708,7 @@ int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, in
     if (rc) return rc;
     if (N == 0) return 0;
     if ((N + RESET_SCAN - 1) / RESET_SCAN > MAX_GRID) return fail(AQUA_E_INVALID, "N=%lld too large for one launch", (long long)N);
-    hipLaunchKernelGGL(reset_tables_kernel, dim3(static_cast<unsigned>((N + RESET_SCAN - 1) / RESET_SCAN)), dim3(BLOCK_SMALL), 0,
+    hipLaunchKernelGGL(reset_tables_kernel, dim3(static_cast<unsigned>((N + RESET_SCAN - 1) / RESET_SCAN)), dim3(BLOCK_SMALL), coop_bytes(K),
                        static_cast<hipStream_t>(stream), a, mask, tab32_dev, tld);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_reset_tables_f32 launch");

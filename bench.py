@@ -855,7 +855,8 @@ def issue_bound(n, args, restarts_per_step):
     tag = library_tag()
     if row.get("library_sha16") != tag:
         return None, "committed budget is of build %s, this is %s" % (row.get("library_sha16"), tag)
-    cycles = (n / 64.0) * row["valu_cycles_stepping_wavefront"] + (restarts_per_step / 8.0) * row["valu_cycles_reseed_pass_per_world_group"]
+    # (a re-seeding pass of a wavefront serves up to eight worlds: restarts / 8 passes at the least)
+    cycles = (n / 64.0) * row["valu_cycles_stepping_wavefront"] + (restarts_per_step / 8.0) * row["valu_cycles_reseed_pass"]
     return cycles / SIMDS / (SHADER_CLOCK_GHZ * 1e3), "%s (build %s)" % (row.get("source"), tag)
 
 

@@ -1452,4 +1452,20 @@ def test_clipped_action_counter(torch):
     acts[2, 1, 7] = 0.19; acts[4, 0, 7] = 0.6; acts[5, 0, env.ld - 1] = 9.0                 # (the last one is padding: not a world)
     env.rollout(6, actions=acts)
     assert int(env.clipped_actions) == 6
+    # replays count too, each with the buffer's content at THAT launch; capturing / preparing counts nothing by itself
+    graph = env.capture_rollout(6, actions=acts)
+    prepared = env.prepare_rollout(6, actions=acts)
+    assert int(env.clipped_actions) == 6
+    graph.launch()
+    assert int(env.clipped_actions) == 8
+    acts[0, 0, 3] = 0.55                                                                     # one more world, from now on
+    graph.launch()
+    prepared.launch()
+    assert int(env.clipped_actions) == 8 + 3 + 3
+    # ... and the counter is part of a checkpoint
+    ckpt = env.state_dict()
+    assert ckpt["clipped_actions"] == 14
+    other = _make(torch, n, presets.NONE, continuous=True, seed=3, count_clipped=True)
+    other.load_state_dict(ckpt)
+    assert int(other.clipped_actions) == 14
     assert _make(torch, n, presets.NONE, continuous=True).clipped_actions is None
