@@ -807,13 +807,10 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const A& a,
 {
     constexpr int WAVES = BLOCK_SMALL / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#ifdef AQUA_DUTY_BY_TICK_ONLY              // (timing experiment: round 3's choice)
-    if (tk.n == 0 || wave != static_cast<int>(tick & (WAVES - 1))) return;
-#else
-    // (a different wavefront every tick AND for every block: wavefront i of every block of a CU runs on SIMD i, and a duty
-    // that depended on the tick alone put the re-seeding passes of all of a CU's blocks on one SIMD)
+    // a different wavefront every tick AND for every block: wavefront i of every block of a CU runs on SIMD i, and a duty
+    // that depended on the tick alone put the re-seeding passes of all of a CU's blocks on one SIMD (fused rollout, next-step
+    // restarts: 4.38 -> 4.05 us per step, profiles/r04/fused_duty/)
     if (tk.n == 0 || wave != static_cast<int>((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1))) return;
-#endif
     uint32_t first[WAVES + 1];
     first[0] = 0;
 #pragma unroll
@@ -852,7 +849,7 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 
 // ------------------------------------------------------------------ one launch per step: no restart, or restart in the same launch
 // Workgroup = TILE_WORLDS lanes, tile = TILE_WORLDS consecutive worlds, one per lane; the per-lane path is the stepping
-// role of step_ns_kernel without the restart markers (same arguments: NsArgs, same addressing, the same late loads).
+// role of step_ns_kernel without the restart markers (same arguments: NsArgs, same addressing; no late loads).
 // RESTART == false (auto_reset 0, the reference's own step(), which never restarts a world): no list, no barrier, no
 // re-seeding code in the kernel.  RESTART == true (auto_reset 1): worlds that finish are not re-seeded by their own lane
 // (that would be 1-2 active lanes per wavefront, in every wavefront, looping over rejection attempts): their tile-local
@@ -883,21 +880,19 @@ __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
     int64_t araw[1] = {2};
     int aidx[1] = {2};
     const uint32_t o4 = o * 4u;
-    const bool late = NS_LATE_LOADS && (wave & 3) != 0;          // see step_ns_kernel
-    const auto issue_loads = [&]() {
-        tin[0] = ld_at(a.time, o4);
-        x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
-        gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
-        wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
-        if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
-        else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
-        else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
-        else if constexpr (AK == AQUA_ACT_F32X2) {
-            avl[0] = ld_at(static_cast<const float*>(a.action), o4);
-            avr[0] = ld_at(a.action_hi, o4);
-        }
-    };
-    if (!late) issue_loads();
+    // every wavefront issues its loads first (step_ns_kernel's late loads lose here: same-step 5.86 -> 6.01 us per step, no
+    // restart 3.56 -> 3.69: sixteen wavefronts of a block already reach the memory system spread out)
+    tin[0] = ld_at(a.time, o4);
+    x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
+    gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
+    wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
+    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
+    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
+    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
+    else if constexpr (AK == AQUA_ACT_F32X2) {
+        avl[0] = ld_at(static_cast<const float*>(a.action), o4);
+        avr[0] = ld_at(a.action_hi, o4);
+    }
     constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;
     const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick = launch_tick(a);
@@ -917,8 +912,6 @@ __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
         if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
         else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
     }
-    asm volatile("" : "+v"(u0[0]), "+v"(u1[0]));
-    if (late) issue_loads();
     asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));   // scheduling fence, see hold_loads()
     hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
     fold_actions<1, AK>(araw, aidx);
@@ -1652,12 +1645,8 @@ __device__ __forceinline__ void serve_reseed_tables(const ReseedTicket& tk, cons
     // table and every sixth world restarting per step a single server was the whole step (126 us per step; the
     // one-launch-per-step kernels 113).
     constexpr int WORLD_WAVES = WPB / 64, SERVERS = WPB == BLOCK_SMALL ? 1 : WAVES - WORLD_WAVES;
-#ifdef AQUA_DUTY_BY_TICK_ONLY
+    // (by tick alone: rotating it by block as serve_reseed() does measured 1-2 % slower here, profiles/r04/fused_duty/)
     const int server = WPB == BLOCK_SMALL ? (wave == static_cast<int>(tick & (WAVES - 1)) ? 0 : -1) : wave - WORLD_WAVES;
-#else
-    const int server = WPB == BLOCK_SMALL ? (wave == static_cast<int>((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1)) ? 0 : -1)
-                                          : wave - WORLD_WAVES;
-#endif
     if (tk.n == 0 || server < 0) return;
     uint32_t first[WAVES + 1];
     first[0] = 0;
