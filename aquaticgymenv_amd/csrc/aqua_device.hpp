@@ -795,13 +795,7 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // of G lanes side by side; every group makes the same G attempts, each against its own SOA_ROWS / SOA_SPLIT rows, and the
 // hits are OR-ed across the groups before anything is decided (a pass over a long table is then SOA_SPLIT times
 // shorter; everything downstream is computed redundantly, and identically, by every group).
-// ROWS == RESEED_COOP: per-world tables of any length, fetched ONCE and by the whole group: lane `sub` loads rows sub,
-// sub + G, ... of the group's world (all of them in flight together: one memory round trip where RESEED_WORLD makes
-// K / 2 dependent ones, two rows at a time inside the attempt loop) and leaves them in the group's LDS slot (`rows`:
-// COOP_SLOT_FLOATS floats, five per row); every lane then tests its candidates against the slot.  No barrier: the slot
-// belongs to one group of one wavefront, whose LDS operations execute in order.
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5, RESEED_HANDOFF16 = -6, RESEED_COOP = -7;
-constexpr int COOP_SLOT_FLOATS = 5 * MAX_OBST;
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5, RESEED_HANDOFF16 = -6;
 template <int G, int ROWS = 0, int SOA_ROWS = 8, int SOA_STRIDE = 256, int SOA_SPLIT = 1>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
@@ -822,29 +816,6 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
     const float W = 0.05f * static_cast<float>(waves);
     const float heading = fmaf(TWO_PI_F, u_01(rw[0]), -PI_F);
 
-    if constexpr (ROWS == RESEED_COOP) {
-        float* const slot = reinterpret_cast<float*>(const_cast<ObstF*>(rows));
-        constexpr int PER_LANE = (MAX_OBST + G - 1) / G;
-        float c[PER_LANE][5];
-#pragma unroll
-        for (int m = 0; m < PER_LANE; ++m) {               // the loads, all of them, first
-            const int j = sub + m * G;
-            if (j < K) {
-                const float* p = wt->t32 + (6 * j) * wt->ld;
-#pragma unroll
-                for (int f = 0; f < 5; ++f) c[m][f] = world_ld(p + f * wt->ld, wt->off);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < PER_LANE; ++m) {
-            const int j = sub + m * G;
-            if (j < K) {
-#pragma unroll
-                for (int f = 0; f < 5; ++f) slot[5 * j + f] = c[m][f];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                   // (compiler: the slot's reads stay behind its writes)
-    }
     float gx = 25.0f, gy = 80.0f, bx = 85.0f, by = 45.0f, bt = 0.0f;
     bool goal_found = !active || !random_goal;
     bool boat_done = !active || !random_boat;
@@ -923,17 +894,6 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 hit_g = ((mg >> sub) & every) != 0ull;
                 hit_b = ((mb >> sub) & every) != 0ull;
             }
-        } else if constexpr (ROWS == RESEED_COOP) {
-            const float* const slot = reinterpret_cast<const float*>(rows);
-#pragma unroll 1
-            for (int j = 0; j < K; j += 2) {             // two rows per LDS wait; an odd K tests its last row twice
-                const float* const r0 = slot + 5 * j;
-                const float* const r1 = slot + 5 * (j + 1 < K ? j + 1 : j);
-                const float c0 = r0[0], c1 = r0[1], c2 = r0[2], c3 = r0[3], c4 = r0[4];
-                const float d0 = r1[0], d1 = r1[1], d2 = r1[2], d3 = r1[3], d4 = r1[4];
-                test(c0, c1, c2, c3, c4);
-                test(d0, d1, d2, d3, d4);
-            }
         } else if constexpr (ROWS == RESEED_WORLD) {
 #pragma unroll 1
             for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
@@ -995,7 +955,7 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_COOP || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_HANDOFF16 || ROWS == RESEED_SOA) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_HANDOFF16 || ROWS == RESEED_SOA) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

@@ -1290,21 +1290,6 @@ struct TablesShared {
     uint32_t count[BLOCK_SMALL / 64];
     uint8_t list[BLOCK_SMALL / 64][64];
 };
-// per-world tables of any length: the rows of a world that is being re-seeded, fetched once by the eight lanes of its group
-// together (reset_env_group<.., RESEED_COOP>): one slot of 5 K floats per group of every wavefront of the block, in
-// DYNAMIC shared memory -- sized by the launch for the table's length (coop_bytes(): 11 KB at 17 rows, 41 KB at 64), so
-// that short tables keep their blocks per CU
-#ifndef AQUA_TABLES_RESEED
-#define AQUA_TABLES_RESEED RESEED_COOP      // (RESEED_WORLD: round 3's form, the rows fetched two at a time inside the attempt loop)
-#endif
-extern __shared__ float coop_rows[];
-struct CoopSlots {
-    int K;
-    __device__ __forceinline__ const ObstF* slot() const
-    {
-        return reinterpret_cast<const ObstF*>(coop_rows + (threadIdx.x / RESET_GROUP) * (5 * K));
-    }
-};
 // Hand-off of a restarting world's table rows from its own lane (which loaded them with its state) to the eight lanes
 // that re-seed it: HANDOFF_PER_WAVE slots per wavefront and round (1.2 worlds of a wavefront restart in a step; a wavefront
 // with more takes another round, block-uniform).  The re-seeding then reads NO memory: with the rows fetched from the
@@ -1481,7 +1466,6 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     } else if constexpr (RESTART) {
         // tables of more than eight rows: the groups read their world's rows from memory
         __shared__ TablesShared sh;
-        const CoopSlots coop{a.K};
         constexpr int WAVES = BLOCK_SMALL / 64;
         const int wave = threadIdx.x >> 6;
         if (done) sh.list[wave][__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(done_ballot >> 32),
@@ -1502,9 +1486,9 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32 + tile, nullptr, tld, i};
-            const EnvState f = reset_env_group<RESET_GROUP, AQUA_TABLES_RESEED>(
+            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
                 active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
-                nullptr, coop.slot(), nullptr, 0, &own);
+                nullptr, nullptr, nullptr, 0, &own);
             if (active && (lane & (RESET_GROUP - 1)) == 0) {
                 st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
                 st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
@@ -1541,7 +1525,6 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
                                                                   float band2, float band2_tight)
 {
     __shared__ ResetShared sh;
-    const CoopSlots coop{a.K};
     tick_housekeeping();
     bool reseed_role;
     uint32_t role;
@@ -1602,9 +1585,9 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
         const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
         const int64_t i = base + local;
         const WorldTable own{t32 + base, nullptr, tld, local};
-        const EnvState f = reset_env_group<RESET_GROUP, AQUA_TABLES_RESEED>(
+        const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
             active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick, a.waves, a.random_boat, a.random_goal, a.K, nullptr,
-            coop.slot(), nullptr, 0, &own);
+            nullptr, nullptr, 0, &own);
         if (active && (lane & (RESET_GROUP - 1)) == 0) {
             st1(a.state + 0 * ld + i, f.x); st1(a.state + 1 * ld + i, f.y); st1(a.state + 2 * ld + i, f.th);
             st1(a.state + 3 * ld + i, f.gx); st1(a.state + 4 * ld + i, f.gy);
@@ -1827,7 +1810,6 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
                                                                    const float* __restrict__ t32, int64_t tld)
 {
     __shared__ ResetShared sh;
-    const CoopSlots coop{a.K};
     constexpr int WAVES = BLOCK_SMALL / 64;
     const uint64_t tick = launch_tick(a);
     const int64_t base = static_cast<int64_t>(blockIdx.x) * RESET_SCAN, ld = a.ld, rem = a.N - base;   // rem > 0
@@ -1882,8 +1864,8 @@ __global__ __launch_bounds__(BLOCK_SMALL) void reset_tables_kernel(const StepArg
         const uint32_t local = active ? sh.list[seg][q - first[seg]] : 0u;         // an idle group reads a world that exists
         const int64_t i = base + local;
         const WorldTable wt{t32 + base, nullptr, tld, local};
-        const EnvState e = reset_env_group<RESET_GROUP, AQUA_TABLES_RESEED>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
-                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, coop.slot(),
+        const EnvState e = reset_env_group<RESET_GROUP, RESEED_WORLD>(active, a.seed, static_cast<uint64_t>(a.env_offset + i), tick,
+                                                                      a.waves, a.random_boat, a.random_goal, a.K, nullptr, nullptr,
                                                                       nullptr, 0, &wt);
         if (active && (lane & (RESET_GROUP - 1)) == 0) store(i, e);
     }
@@ -2505,8 +2487,6 @@ int fill_table_args(StepArgs& a, const AquaParams* p, const float* tab32, int K,
 }  // namespace
 
 namespace {
-size_t coop_bytes(int K) { return static_cast<size_t>(BLOCK_SMALL / RESET_GROUP) * 5u * static_cast<size_t>(K) * sizeof(float); }
-
 struct TableArgs {
     const float* t32;
     const double* t64;
@@ -2536,9 +2516,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     }
     if (blocks > MAX_GRID) return hipErrorInvalidValue;
     const dim3 grid(static_cast<unsigned>(blocks)), block(BLOCK_SMALL);
-    // the kernels whose re-seeding groups fetch their world's rows together (tables that are not held in registers)
-    const size_t coop = (!regs && a.auto_reset != 0) ? coop_bytes(a.K) : 0;
-#define AQUA_TAB_ARGS grid, block, coop, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight
+#define AQUA_TAB_ARGS grid, block, 0, s, a, t.t32, t.t64, t.tld, t.band2, t.band2_tight
 #define AQUA_TAB_LAUNCH(AK)                                                                                        \
     case AK:                                                                                                        \
         if (ns_tile && wide) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
@@ -2697,7 +2675,7 @@ int aqua_reset_tables_f32(const AquaParams* p, const float* tab32_dev, int K, in
     if (rc) return rc;
     if (N == 0) return 0;
     if ((N + RESET_SCAN - 1) / RESET_SCAN > MAX_GRID) return fail(AQUA_E_INVALID, "N=%lld too large for one launch", (long long)N);
-    hipLaunchKernelGGL(reset_tables_kernel, dim3(static_cast<unsigned>((N + RESET_SCAN - 1) / RESET_SCAN)), dim3(BLOCK_SMALL), coop_bytes(K),
+    hipLaunchKernelGGL(reset_tables_kernel, dim3(static_cast<unsigned>((N + RESET_SCAN - 1) / RESET_SCAN)), dim3(BLOCK_SMALL), 0,
                        static_cast<hipStream_t>(stream), a, mask, tab32_dev, tld);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_reset_tables_f32 launch");
