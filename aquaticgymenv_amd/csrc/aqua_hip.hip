@@ -994,17 +994,20 @@ __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
     }
 }
 
-// ------------------------------------------------------------------ one launch per step, next-step restart, batches of millions
-// step_ns_kernel splits the launch by role so that nothing of a restart is on the path of a launch that is a few
-// microseconds long; the price is eight scattered 4-byte stores per restarted world (every one a 32-byte sector on its
-// way to HBM: writes 1.16x the algorithmic bytes at 16.7 M worlds) and blocks that only scan and re-seed.  In a batch of
-// millions of worlds a block's own latency no longer matters -- the next block of the grid fills the gap -- and the
-// traffic does.  step_tile_kernel keeps the restart INSIDE the 256-world tile, with the fused rollout's protocol: the lanes of
-// the worlds to restart publish themselves on an LDS list (one barrier), ONE wavefront of the block (a different one
-// every tick) re-seeds them eight lanes per world while the others step their worlds, the owners pick the fresh states up
-// behind a second barrier and store them with the tile's coalesced row stores (the goal rows, which no stepping lane
-// writes, as a masked store of their own: two sectors per restart instead of eight).  No re-seeding blocks, no second
-// read of the time row.  Markers, draws and results are step_ns_kernel's bit for bit (Philox is keyed by world and tick).
+// ------------------------------------------------------------------ one launch per step, same-step restart, batches of millions
+// step_kernel's restart costs eight scattered 4-byte stores per restarted world (every one a 32-byte sector on its way to
+// HBM) and a barrier of sixteen wavefronts.  In a batch of millions of worlds a block's own latency no longer matters --
+// the next block of the grid fills the gap -- and the traffic does.  step_tile_kernel keeps the restart inside a 256-world
+// tile with the fused rollout's protocol: the lanes of the worlds to restart publish themselves on an LDS list (ballots,
+// one barrier of four wavefronts), ONE wavefront of the block re-seeds them eight lanes per world, the owners pick the
+// fresh states up behind a second barrier and store them with the tile's coalesced row stores (the goal rows, which no
+// stepping lane writes, as a masked store of their own: two sectors per restart instead of eight).  Bit-identical to
+// step_kernel (Philox is keyed by world and tick).  It wins where the batch streams (profiles/r04/same_step_tile/) and
+// loses where a launch is a few rounds of blocks (262 144 worlds: 7.5 against 5.9 us per step).
+// (The same protocol for the NEXT-step restart -- no re-seeding blocks, no second read of the time row, whole-line stores
+// -- was built, is bit-identical to step_ns_kernel and loses to it at every batch size, 524 288 to 16.7 M worlds: the
+// role-split launch keeps the restart off the stepping wavefronts' path, and that is worth more than the write traffic;
+// profiles/r04/in_tile_restart/ holds its patch and timings.)
 struct NsTileShared {
     RolloutShared r;
     ObstF rows[NS_TABLE_ROWS > 0 ? NS_TABLE_ROWS : 1];       // small tables: the re-seeding pass reads them from here
@@ -1047,16 +1050,9 @@ __device__ __forceinline__ void serve_tile(const ReseedTicket& tk, const NsArgs&
     }
 }
 
-// MODE: AQUA_RESET_NEXT_STEP (batches of millions, above) or AQUA_RESET_SAME_STEP: the worlds that finish in this launch
-// are re-seeded in it (draws of this tick) -- the same protocol behind the step instead of beside it: the list by
-// ballots instead of atomics, a barrier of four wavefronts instead of sixteen, and the fresh states stored by their own
-// lanes with the tile's row stores instead of eight scattered words (step_kernel's same-step form: 6.3 us per step at
-// 262 144 worlds, of which list + barrier 0.86, scattered stores 0.45; profiles/r03/ab_same_step.txt).
-template <int AK, bool SMALL_TABLE, bool WB, int MODE>
+template <int AK, bool SMALL_TABLE, bool WB>
 __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void step_tile_kernel(const NsArgs a)
 {
-    static_assert(MODE == AQUA_RESET_NEXT_STEP || MODE == AQUA_RESET_SAME_STEP, "a restart mode");
-    constexpr bool NEXT = MODE == AQUA_RESET_NEXT_STEP;
     __shared__ NsTileShared sh;
     tick_housekeeping<NsArgs>();
     const uint32_t tile = blockIdx.x * NS_TILE;
@@ -1088,24 +1084,9 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
     if (SMALL_TABLE && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
         table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
     const uint64_t tick = launch_tick(a);
-    int32_t t0 = tin[0];
-    bool restart = false, pending = false;
-    ReseedTicket tk{0u, 0u};
-    if constexpr (NEXT) {
-        asm volatile("" : "+v"(tin[0]));
-        // the markers of step_ns_kernel: restarted last tick -> steps from 0; finished last tick -> restarts now; any
-        // other marker waits
-        t0 = tin[0] == restart_code(tick - 1) ? 0 : tin[0];
-        restart = valid && tin[0] == done_code(tick - 1);
-        pending = valid && t0 < 0;
-    }
     if (SMALL_TABLE && threadIdx.x < NS_TABLE_ROWS * 8) {
         const bool present = threadIdx.x < static_cast<uint32_t>(a.K) * 8;
         reinterpret_cast<uint32_t*>(sh.rows)[threadIdx.x] = present ? table_word : ((threadIdx.x & 7u) == 4u ? 0xFF61B1E6u : 0u);
-    }
-    if constexpr (NEXT) {
-        tk = publish_reseed(restart, sh.r, 0);          // (one barrier: the list and the table are in place)
-        serve_tile<SMALL_TABLE>(tk, a, tick, tile, sh);  // the duty wavefront; the others go straight on
     }
     // ---- every wavefront steps its worlds
     constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;
@@ -1125,16 +1106,16 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
         else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
     }
-    if constexpr (!NEXT) asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));      // the draws run in the loads' shadow
+    asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));      // the draws run in the loads' shadow
     hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
     fold_actions<1, AK>(araw, aidx);
     if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
     const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
-    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], NEXT ? t0 : tin[0]};
+    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], tin[0]};
     const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
     float rew;
     uint32_t code;
-    const bool live = valid && !pending;
+    const bool live = valid;
     asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));
     const bool knife = fast_step<false, QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
     if (__builtin_expect(any_lane(knife), 0)) {
@@ -1144,8 +1125,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
             e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
         }
     }
-    if (!live) { rew = 0.0f; code = 0u; }              // a restarting (or padding) world reports reward 0, term 0
-    const bool done = code != 0u;
+    const bool done = live && code != 0u;
     constexpr bool wb = WB;
     if (valid) {
         st_at(a.reward, o4, rew, wb);
@@ -1159,22 +1139,19 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
             else st1(a.done_bits + word, b);
         }
     }
-    int32_t t_out = (NEXT && done) ? done_code(tick) : e.t;
-    if constexpr (!NEXT) {
-        restart = done;                                 // (done implies valid)
-        tk = publish_reseed(restart, sh.r, 0);
-        serve_tile<SMALL_TABLE>(tk, a, tick, tile, sh);
-    }
+    int32_t t_out = e.t;
+    const ReseedTicket tk = publish_reseed(done, sh.r, 0);        // (one barrier: the list and the table are in place)
+    serve_tile<SMALL_TABLE>(tk, a, tick, tile, sh);                // the duty wavefront
     if (tk.n != 0) {                                    // block-uniform
         __syncthreads();
-        if (restart) {
+        if (done) {
             const float* r = sh.r.result[tk.slot];
             e.x = r[0]; e.y = r[1]; e.th = r[2]; e.gx = r[3]; e.gy = r[4]; e.wx = r[5]; e.wy = r[6];
-            t_out = NEXT ? restart_code(tick) : 0;
+            t_out = 0;
             st_at(a.row[3], o4, e.gx, wb); st_at(a.row[4], o4, e.gy, wb);      // the only rows a stepping lane never writes
         }
     }
-    if (live || restart) {                              // the tile's row stores, whole lines wherever no lane waits
+    if (live) {                                         // the tile's row stores: whole lines
         st_at(a.row[0], o4, e.x, wb); st_at(a.row[1], o4, e.y, wb); st_at(a.row[2], o4, e.th, wb);
         st_at(a.row[5], o4, e.wx, wb); st_at(a.row[6], o4, e.wy, wb);
         st_at(a.time, o4, t_out, wb);
@@ -2075,10 +2052,10 @@ hipError_t launch_step(const StepArgs& a0, int kind, hipStream_t s, const Launch
     case AK:                                                                                                                     \
         if (plain && small) launch_kernel((step_kernel<AK, true, false>), grid, block, s, e, a);                                 \
         else if (plain) launch_kernel((step_kernel<AK, false, false>), grid, block, s, e, a);                                    \
-        else if (in_tile && small && wb) launch_kernel((step_tile_kernel<AK, true, true, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);   \
-        else if (in_tile && small) launch_kernel((step_tile_kernel<AK, true, false, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);        \
-        else if (in_tile && wb) launch_kernel((step_tile_kernel<AK, false, true, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);           \
-        else if (in_tile) launch_kernel((step_tile_kernel<AK, false, false, AQUA_RESET_SAME_STEP>), grid, block, s, e, a);                \
+        else if (in_tile && small && wb) launch_kernel((step_tile_kernel<AK, true, true>), grid, block, s, e, a);   \
+        else if (in_tile && small) launch_kernel((step_tile_kernel<AK, true, false>), grid, block, s, e, a);        \
+        else if (in_tile && wb) launch_kernel((step_tile_kernel<AK, false, true>), grid, block, s, e, a);           \
+        else if (in_tile) launch_kernel((step_tile_kernel<AK, false, false>), grid, block, s, e, a);                \
         else if (small && wb) launch_kernel((step_kernel<AK, true, true, true>), grid, block, s, e, a);                          \
         else if (wb) launch_kernel((step_kernel<AK, false, true, true>), grid, block, s, e, a);                                  \
         else if (small) launch_kernel((step_kernel<AK, true, true>), grid, block, s, e, a);                                      \
