@@ -856,9 +856,11 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 // indices go on a list in LDS (one private segment per wavefront: ballot + prefix count) and, after ONE barrier, groups of
 // RESET_GROUP lanes re-seed them densely (reset_env_group, draws of this tick) and write the fresh state straight to
 // HBM; the owning lane skips its state stores for that world.  Tiles of 1024 worlds: 512 / 256 are slower here (6.46 /
-// 6.66 / 7.00 us per step, profiles/r03/ab_tile_worlds.txt), and so is the in-tile hand-off of step_tile_kernel at this
-// batch size (7.5 us: profiles/r04/same_step_tile/) -- a launch that is one round of blocks wants the lanes' own stores
-// out ahead of the barrier and the re-seeding from scalar operands.
+// 6.66 / 7.00 us per step, profiles/r03/ab_tile_worlds.txt), and so are 256-world tiles whose restarted worlds are handed
+// back to their own lanes through LDS and stored with the tile's coalesced row stores (the fused rollout's protocol:
+// bit-identical, 7.5 us at 262 144 worlds, and behind this kernel at every size up to 16.7 M: profiles/r04/same_step_tile/)
+// -- the lanes' own stores out ahead of the barrier and the re-seeding from scalar operands are worth more than the
+// scattered words they cost.
 struct TileShared {
     uint32_t count[TILE_WORLDS / 64];
     uint16_t list[TILE_WORLDS / 64][64];
@@ -991,171 +993,6 @@ __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
                 ns_write_norm(a, i4, f.x, f.y, f.th, f.gx, f.gy, wb);
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------ one launch per step, same-step restart, batches of millions
-// step_kernel's restart costs eight scattered 4-byte stores per restarted world (every one a 32-byte sector on its way to
-// HBM) and a barrier of sixteen wavefronts.  In a batch of millions of worlds a block's own latency no longer matters --
-// the next block of the grid fills the gap -- and the traffic does.  step_tile_kernel keeps the restart inside a 256-world
-// tile with the fused rollout's protocol: the lanes of the worlds to restart publish themselves on an LDS list (ballots,
-// one barrier of four wavefronts), ONE wavefront of the block re-seeds them eight lanes per world, the owners pick the
-// fresh states up behind a second barrier and store them with the tile's coalesced row stores (the goal rows, which no
-// stepping lane writes, as a masked store of their own: two sectors per restart instead of eight).  Bit-identical to
-// step_kernel (Philox is keyed by world and tick).  It wins where the batch streams (profiles/r04/same_step_tile/) and
-// loses where a launch is a few rounds of blocks (262 144 worlds: 7.5 against 5.9 us per step).
-// (The same protocol for the NEXT-step restart -- no re-seeding blocks, no second read of the time row, whole-line stores
-// -- was built, is bit-identical to step_ns_kernel and loses to it at every batch size, 524 288 to 16.7 M worlds: the
-// role-split launch keeps the restart off the stepping wavefronts' path, and that is worth more than the write traffic;
-// profiles/r04/in_tile_restart/ holds its patch and timings.)
-struct NsTileShared {
-    RolloutShared r;
-    ObstF rows[NS_TABLE_ROWS > 0 ? NS_TABLE_ROWS : 1];       // small tables: the re-seeding pass reads them from here
-};
-
-// the duty wavefront of a tile re-seeds the worlds on the tile's list (publish_reseed) and leaves the fresh states in LDS.
-// Which wavefront: a different one every tick AND for every block -- wavefront i of every block of a CU runs on SIMD i,
-// so a duty that depended on the tick alone would put the re-seeding passes of all of a CU's blocks on one SIMD.
-template <bool SMALL_TABLE>
-__device__ __forceinline__ void serve_tile(const ReseedTicket& tk, const NsArgs& a, uint64_t tick, uint32_t tile, NsTileShared& sh)
-{
-    constexpr int WAVES = NS_MAIN_WAVES;
-    const int lane = threadIdx.x & 63;
-    if (tk.n == 0 || (threadIdx.x >> 6) != ((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1))) return;
-    uint32_t first[WAVES + 1];
-    first[0] = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.r.count[0][w];
-    const int waves = args_waves(a), random_boat = args_random_boat(a), random_goal = args_random_goal(a);
-    const uint64_t env_base = static_cast<uint64_t>(a.env_offset) + tile;
-    constexpr uint32_t PER_PASS = 64 / NS_RESEED_GROUP;
-    for (uint32_t qb = 0; qb < tk.n; qb += PER_PASS) {
-        const uint32_t q = qb + (lane / NS_RESEED_GROUP);
-        const bool active = q < tk.n;
-        uint32_t seg = 0;
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
-        const uint32_t owner = sh.r.list[0][seg][active ? q - first[seg] : 0];
-        EnvState f;
-        if constexpr (SMALL_TABLE)
-            f = reset_env_group<NS_RESEED_GROUP, NS_TABLE_ROWS>(active, a.seed, env_base + owner, tick, waves, random_boat, random_goal,
-                                                                a.K, obstacle_rows(a.obst_blob), sh.rows);
-        else
-            f = reset_env_group<NS_RESEED_GROUP>(active, a.seed, env_base + owner, tick, waves, random_boat, random_goal, a.K,
-                                                 obstacle_rows(a.obst_blob));
-        if (active && (lane & (NS_RESEED_GROUP - 1)) == 0) {
-            float* r = sh.r.result[q];
-            r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
-        }
-    }
-}
-
-template <int AK, bool SMALL_TABLE, bool WB>
-__global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void step_tile_kernel(const NsArgs a)
-{
-    __shared__ NsTileShared sh;
-    tick_housekeeping<NsArgs>();
-    const uint32_t tile = blockIdx.x * NS_TILE;
-    const uint32_t rem = a.N - tile;                   // >= 1
-    const int lane = threadIdx.x & 63;
-    const uint32_t last = (rem < NS_TILE ? rem : static_cast<uint32_t>(NS_TILE)) - 1u;
-    const uint32_t off = threadIdx.x;
-    const bool valid = off < rem;
-    const uint32_t o = tile + (off < last ? off : last);
-    float x[1], y[1], th[1], gx[1], gy[1], wx[1], wy[1], u0[1] = {0.0f}, u1[1] = {0.0f}, avl[1] = {0.5f}, avr[1] = {0.5f};
-    int32_t tin[1];
-    int64_t araw[1] = {2};
-    int aidx[1] = {2};
-    const uint32_t o4 = o * 4u;
-    tin[0] = ld_at(a.time, o4);
-    x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);
-    gx[0] = ld_at(a.row[3], o4); gy[0] = ld_at(a.row[4], o4);
-    wx[0] = ld_at(a.row[5], o4); wy[0] = ld_at(a.row[6], o4);
-    if constexpr (AK == AQUA_ACT_U8) araw[0] = ld_at(static_cast<const uint8_t*>(a.action), o);
-    else if constexpr (AK == AQUA_ACT_I32) araw[0] = ld_at(static_cast<const int32_t*>(a.action), o4);
-    else if constexpr (AK == AQUA_ACT_I64) araw[0] = ld_at(static_cast<const int64_t*>(a.action), o * 8u);
-    else if constexpr (AK == AQUA_ACT_F32X2) {
-        avl[0] = ld_at(static_cast<const float*>(a.action), o4);
-        avr[0] = ld_at(a.action_hi, o4);
-    }
-    // small tables go to LDS for the re-seeding pass, as in step_ns_kernel's re-seeding blocks (one vector load per lane,
-    // in flight with the state; the quick table's SGPR operands are the stepping path's)
-    uint32_t table_word = 0;
-    if (SMALL_TABLE && threadIdx.x < NS_TABLE_ROWS * 8 && threadIdx.x < static_cast<uint32_t>(a.K) * 8)
-        table_word = ld1(reinterpret_cast<const uint32_t*>(static_cast<const char*>(a.obst_blob) + sizeof(ObstHeader)) + threadIdx.x);
-    const uint64_t tick = launch_tick(a);
-    if (SMALL_TABLE && threadIdx.x < NS_TABLE_ROWS * 8) {
-        const bool present = threadIdx.x < static_cast<uint32_t>(a.K) * 8;
-        reinterpret_cast<uint32_t*>(sh.rows)[threadIdx.x] = present ? table_word : ((threadIdx.x & 7u) == 4u ? 0xFF61B1E6u : 0u);
-    }
-    // ---- every wavefront steps its worlds
-    constexpr int QUICK = SMALL_TABLE ? QUICK_ALWAYS : QUICK_NEVER;
-    const StepConst k = make_const<QUICK>(a, obstacle_rows(a.obst_blob));
-    const uint64_t env0 = (static_cast<uint64_t>(a.env_offset) + tile) + off;
-    if (__builtin_expect(!(a.flags & NS_HAS_NOISE), 1)) {
-        uint32_t w0[1], w1[1];
-        pair_draws<1>(a.seed, env0, tick, STREAM_STEP, w0, w1);
-        u0[0] = u_pm1(w0[0]); u1[0] = u_pm1(w1[0]);
-    } else {
-        u0[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise)), o4);
-        u1[0] = ld_at(kernarg_at<const float*>(offsetof(NsArgs, noise) + sizeof(float*)), o4);
-    }
-    if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
-        uint32_t w0[1], w1[1];
-        pair_draws<1, false>(a.seed, env0, tick, STREAM_ACT, w0, w1);
-        if constexpr (AK == AQUA_ACT_SAMPLE_D) aidx[0] = sample_discrete(w0[0]);
-        else { avl[0] = sample_thrust(w0[0]); avr[0] = sample_thrust(w1[0]); }
-    }
-    asm volatile("" : "+v"(tin[0]), "+v"(u0[0]), "+v"(u1[0]));      // the draws run in the loads' shadow
-    hold_loads<1, AK>(x, y, th, gx, gy, wx, wy, araw, avl, avr);
-    fold_actions<1, AK>(araw, aidx);
-    if constexpr (AK == AQUA_ACT_BEARING) aidx[0] = bearing_action(x[0], y[0], th[0], gx[0], gy[0]);
-    const float x0 = x[0], y0 = y[0], th0 = th[0], wx0 = wx[0], wy0 = wy[0];
-    EnvState e{x[0], y[0], th[0], gx[0], gy[0], wx[0], wy[0], tin[0]};
-    const Motion mo = decode_motion<AK>(k, aidx[0], avl[0], avr[0]);
-    float rew;
-    uint32_t code;
-    const bool live = valid;
-    asm volatile("" ::"s"(k.touch[0]), "s"(k.touch[1]), "s"(k.touch[2]), "s"(k.touch[3]));
-    const bool knife = fast_step<false, QUICK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code) && live;
-    if (__builtin_expect(any_lane(knife), 0)) {
-        if (knife) {
-            const ExactOut o2 = exact_step(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.obst64,
-                                           k.obst, k.band2, k.time_limit);
-            e.x = o2.x; e.y = o2.y; e.th = o2.th; rew = o2.reward; code = o2.term;
-        }
-    }
-    const bool done = live && code != 0u;
-    constexpr bool wb = WB;
-    if (valid) {
-        st_at(a.reward, o4, rew, wb);
-        st_at(a.term, o, static_cast<uint8_t>(code), wb);
-    }
-    if (a.done_bits != nullptr) {
-        const uint64_t b = __ballot(done);
-        const uint32_t word = (tile >> 6) + (uni(off) >> 6);
-        if (word < ((a.N + 63u) >> 6) && lane == 0) {
-            if (a.flags & NS_DONE_WORD_WB) a.done_bits[word] = b;
-            else st1(a.done_bits + word, b);
-        }
-    }
-    int32_t t_out = e.t;
-    const ReseedTicket tk = publish_reseed(done, sh.r, 0);        // (one barrier: the list and the table are in place)
-    serve_tile<SMALL_TABLE>(tk, a, tick, tile, sh);                // the duty wavefront
-    if (tk.n != 0) {                                    // block-uniform
-        __syncthreads();
-        if (done) {
-            const float* r = sh.r.result[tk.slot];
-            e.x = r[0]; e.y = r[1]; e.th = r[2]; e.gx = r[3]; e.gy = r[4]; e.wx = r[5]; e.wy = r[6];
-            t_out = 0;
-            st_at(a.row[3], o4, e.gx, wb); st_at(a.row[4], o4, e.gy, wb);      // the only rows a stepping lane never writes
-        }
-    }
-    if (live) {                                         // the tile's row stores: whole lines
-        st_at(a.row[0], o4, e.x, wb); st_at(a.row[1], o4, e.y, wb); st_at(a.row[2], o4, e.th, wb);
-        st_at(a.row[5], o4, e.wx, wb); st_at(a.row[6], o4, e.wy, wb);
-        st_at(a.time, o4, t_out, wb);
-        ns_write_norm(a, o4, e.x, e.y, e.th, e.gx, e.gy, wb);
     }
 }
 
@@ -2023,20 +1860,11 @@ void launch_kernel(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, const La
 
 void fill_ns_args(NsArgs& a, const StepArgs& a0, int kind, int64_t first, int64_t n, bool housekeeping_head, bool housekeeping_tail);
 
-// same-step restart: batches of at least this many worlds restart inside 256-world tiles with the hand-off of
-// step_tile_kernel (whole-line stores) instead of step_kernel's 1024-world tiles
-#ifndef AQUA_SS_TILE_MIN
-#define AQUA_SS_TILE_MIN INT64_MAX
-#endif
-constexpr int64_t SAME_STEP_TILE_MIN = AQUA_SS_TILE_MIN;
-
-// auto_reset 0 / 1: step_kernel (or, same-step restart of a large batch, step_tile_kernel), one launch per
-// NS_LAUNCH_MAX_WORLDS worlds
+// auto_reset 0 / 1: step_kernel, one launch per NS_LAUNCH_MAX_WORLDS worlds
 hipError_t launch_step(const StepArgs& a0, int kind, hipStream_t s, const LaunchEvents& ev = {})
 {
     const bool plain = a0.auto_reset == 0;              // no restart: no list, no barrier, no re-seeding code in the kernel
     const bool wb = !plain && a0.N >= STORE_WB_SAME_STEP_MIN;
-    const bool in_tile = !plain && a0.N >= SAME_STEP_TILE_MIN;
     const bool small = NS_TABLE_ROWS > 0 && a0.K <= NS_TABLE_ROWS;
     for (int64_t first = 0; first < a0.N; first += NS_LAUNCH_MAX_WORLDS) {
         const int64_t n = a0.N - first < NS_LAUNCH_MAX_WORLDS ? a0.N - first : NS_LAUNCH_MAX_WORLDS;
@@ -2046,16 +1874,11 @@ hipError_t launch_step(const StepArgs& a0, int kind, hipStream_t s, const Launch
         if (tail) e.stop = ev.stop;
         NsArgs a;
         fill_ns_args(a, a0, kind, first, n, head, tail);
-        const int worlds_per_block = in_tile ? NS_TILE : TILE_WORLDS;
-        const dim3 grid(static_cast<unsigned>((n + worlds_per_block - 1) / worlds_per_block)), block(worlds_per_block);
+        const dim3 grid(static_cast<unsigned>((n + TILE_WORLDS - 1) / TILE_WORLDS)), block(TILE_WORLDS);
 #define AQUA_STEP_LAUNCH(AK)                                                                                                     \
     case AK:                                                                                                                     \
         if (plain && small) launch_kernel((step_kernel<AK, true, false>), grid, block, s, e, a);                                 \
         else if (plain) launch_kernel((step_kernel<AK, false, false>), grid, block, s, e, a);                                    \
-        else if (in_tile && small && wb) launch_kernel((step_tile_kernel<AK, true, true>), grid, block, s, e, a);   \
-        else if (in_tile && small) launch_kernel((step_tile_kernel<AK, true, false>), grid, block, s, e, a);        \
-        else if (in_tile && wb) launch_kernel((step_tile_kernel<AK, false, true>), grid, block, s, e, a);           \
-        else if (in_tile) launch_kernel((step_tile_kernel<AK, false, false>), grid, block, s, e, a);                \
         else if (small && wb) launch_kernel((step_kernel<AK, true, true, true>), grid, block, s, e, a);                          \
         else if (wb) launch_kernel((step_kernel<AK, false, true, true>), grid, block, s, e, a);                                  \
         else if (small) launch_kernel((step_kernel<AK, true, true>), grid, block, s, e, a);                                      \
