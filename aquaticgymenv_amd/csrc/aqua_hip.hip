@@ -1,27 +1,31 @@
 // aqua_hip.hip -- kernels and C ABI (include/aqua_hip.h) of the batched AquaEnv hot path, gfx950 only.
 //
 // Kernels (reference: AquaEnv.step, gym_aqua/envs/aqua.py:135-213; AquaEnv.reset, aqua.py:100-126)
-//   step_ns_kernel<AK, SMALL_TABLE, INTERLEAVE>  one launch per batched step, next-step restart (auto_reset 2): the launch
-//                          is split by role -- re-seeding blocks (at the head of a one-round grid; one in every five
+//   step_ns_kernel<AK, SMALL_TABLE, INTERLEAVE, WB>  one launch per batched step, next-step restart (auto_reset 2): the
+//                          launch is split by role -- re-seeding blocks (at the head of a one-round grid; one in every five
 //                          blocks, on the XCD of its stepping neighbours, in larger grids) and stepping blocks of 256
 //                          worlds (one per lane) -- with no synchronisation between the two.  The benchmarked kernel.
-//   step_kernel<AK, SMALL, RESTART>  one launch per batched step, no restart (auto_reset 0) or restart in the same launch
-//                          (auto_reset 1): 1024-world tiles, finished worlds re-seeded after one barrier.
+//   step_kernel<AK, SMALL_TABLE, RESTART, WB>  one launch per batched step, no restart (auto_reset 0) or restart in the
+//                          same launch (auto_reset 1): 1024-world tiles, finished worlds re-seeded after one barrier.
+//                          Both take NsArgs (their own slim kernel arguments); every other kernel takes StepArgs.
 //   rollout_kernel<AK>     T steps in one launch with the world state held in registers.
-//   step_tables_kernel / step_tables_ns_kernel / reset_tables_kernel   the same three for batches in which every world
-//                          has its own obstacle table.
+//   step_tables_kernel / step_tables_ns_kernel / reset_tables_kernel / rollout_tables*_kernel   the same for batches in
+//                          which every world has its own obstacle table.
 //   reset_kernel           masked reset.   obs_norm_kernel  the DQN's normalised observation after a reset.
 //   ring_write_kernel<T>   one batch of rows into consecutive slots of a replay ring.
+//   copy_words_kernel / copy_fanout_kernel   the done-mask blocks' way into (IPC-mapped) receive buffers.
 //   tick_kernel            *tick_base += delta (tail node of a captured fused rollout or one-step graph; the per-step
 //                          rollouts advance their tick base themselves, tick_housekeeping()).
 // All of it is coalesced float/integer streaming work on struct-of-arrays rows; no MFMA anywhere (there is
 // no contraction to feed it).  Arithmetic shared by the kernels lives in aqua_device.hpp.
 //
-// Build-time switches (diagnostic builds only, aquaticgymenv_amd/build.py build_variant(); never defined in the shipped
-// library): AQUA_STAMPS = 1 | 2 (in-kernel phase stamps + the micro-benchmark kernels of csrc/aqua_tuning.inc, tools/stamps*.py,
-// tools/reseed_bench.py, tools/skeleton.py), AQUA_NS_NOWORK / AQUA_NS_NOMAIN (one role of the next-step kernel alone,
-// tools/sweep_n.sh).  The tuning constants below (tile sizes, group sizes, cache scopes) are plain constants: every
-// alternative that was measured is recorded with its timing in DESIGN.md section 5.3.
+// Build-time switches (diagnostic / development builds only, aquaticgymenv_amd/build.py build_variant(); never defined in
+// the shipped library): AQUA_STAMPS = 1 | 2 | 3 (in-kernel phase stamps + the micro-benchmark kernels of
+// csrc/aqua_tuning.inc), AQUA_NS_NOWORK / AQUA_NS_NOMAIN (one role of the next-step kernel alone), AQUA_ST1_PLAIN,
+// AQUA_NS_LATE_LOADS=0 (the next-step kernel without its late loads), AQUA_DEV_U8_ONLY (one action kind instead of
+// seven: a sixth of the compile time while a kernel is being worked on).  The tuning constants below (tile sizes, group
+// sizes, cache scopes) are plain constants: every alternative that was measured is recorded with its timing in
+// profiles/LOG.md.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -460,7 +464,7 @@ __device__ __forceinline__ void tick_housekeeping()
 constexpr int NS_MAIN_WAVES = 4;
 constexpr int NS_TILE = NS_MAIN_WAVES * 64, NS_BLOCK = NS_TILE;
 constexpr int NS_SCAN_ROWS = 4, NS_SCAN = NS_SCAN_ROWS * NS_BLOCK;      // worlds per re-seeding block
-constexpr int NS_RESEED_GROUP = 8;
+constexpr int NS_RESEED_GROUP = 8;       // (4 / 8 / 16 lanes per restarting world: 6.95 / 4.72 / 5.54 us; 16.7 M worlds: within the noise)
 // Late loads.  A launch that is ONE round of blocks has two phases -- every wavefront waits for its nine rows (1.6 us of
 // fabric traffic), then every wavefront computes -- and neither overlaps the other.  Three wavefronts of four therefore
 // issue their loads BEHIND their Philox draws instead of ahead of them: their requests reach the memory system a few
@@ -468,7 +472,7 @@ constexpr int NS_RESEED_GROUP = 8;
 // worlds (profiles/r04/stagger/): 4.89 -> 4.71 us; half of the wavefronts 4.74, one of four 4.82, all of them 4.84; any
 // s_sleep in front of the late loads loses (4.98-5.28).
 #ifndef AQUA_NS_LATE_LOADS
-#define AQUA_NS_LATE_LOADS 1
+#define AQUA_NS_LATE_LOADS 1            // (0: a timing build without them, tools/ab.py)
 #endif
 constexpr bool NS_LATE_LOADS = AQUA_NS_LATE_LOADS != 0;
 static_assert(NS_SCAN <= 65536, "list entries are 16-bit offsets");
@@ -509,7 +513,8 @@ __device__ __forceinline__ void ns_write_norm(const NsArgs& a, uint32_t byte_off
 template <bool SMALL_TABLE, bool WB>
 __device__ __forceinline__ void ns_reseed_block(const NsArgs& a, uint32_t block, NsReseedShared& sh)
 {
-    __builtin_amdgcn_s_setprio(3);                      // the longest chain of the launch: issue first
+    __builtin_amdgcn_s_setprio(3);                      // the longest chain of the launch: issue first (priority 0 / 1 / 3:
+                                                        // 4.72 each since the late loads, profiles/r04/late_loads/)
     const uint32_t base = block * NS_SCAN;              // the block's first world; every access below is row pointer +
     const uint32_t rem = a.N - base;                    // 32-bit byte offset (> 0)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -617,7 +622,7 @@ __device__ __forceinline__ bool ns_role(uint32_t reseed_blocks, uint32_t n_tiles
         if (group >= reseed_blocks) return false;              // the grid is rounded up to whole sets of 8 groups
         if (!reseed_role && role_index >= n_tiles) return false;   // the last group may be short of stepping tiles
     } else {
-        reseed_role = blockIdx.x < reseed_blocks;
+        reseed_role = blockIdx.x < reseed_blocks;      // (at the tail of the grid instead: 4.72 -> 4.75 us)
         role_index = reseed_role ? blockIdx.x : blockIdx.x - reseed_blocks;
     }
     return true;
@@ -659,11 +664,9 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     int64_t araw[1] = {2};
     int aidx[1] = {2};
     const uint32_t o4 = o * 4u;                         // byte offset inside a float / int row
-#ifndef AQUA_NS_LATE_INTERLEAVE
-#define AQUA_NS_LATE_INTERLEAVE 0
-#endif
-    // late loads (NS_LATE_LOADS above): wavefronts 1-3 of the block issue theirs behind the draws
-    const bool late = NS_LATE_LOADS && (!INTERLEAVE || AQUA_NS_LATE_INTERLEAVE) && (threadIdx.x >> 6) != 0u;
+    // late loads (NS_LATE_LOADS above): wavefronts 1-3 of the block issue theirs behind the draws -- in the one-round layout
+    // only (the interleaved grids of large batches are staggered by themselves: 524 288 worlds 8.30 -> 8.67 us with them)
+    const bool late = NS_LATE_LOADS && !INTERLEAVE && (threadIdx.x >> 6) != 0u;
     const auto issue_loads = [&]() {
         tin[0] = ld_at(a.time, o4);
         x[0] = ld_at(a.row[0], o4); y[0] = ld_at(a.row[1], o4); th[0] = ld_at(a.row[2], o4);

@@ -391,6 +391,37 @@ def test_large_batch_store_policy_equals_its_shards(torch, mode):
     assert ended > n // 20, "the rollout must exercise the restart path"
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["no_restart", "same_step", "next_step"])
+def test_a_batch_beyond_one_launch_is_split_and_equals_its_shards(torch, mode):
+    """The step kernels address a world by a 32-bit byte offset from the row pointers of their launch, so the library steps
+    a batch of more than 2^28 worlds as several launches (aqua_hip.hip, NS_LAUNCH_MAX_WORLDS), each with its own pointers,
+    env_offset and tick housekeeping.  268 M worlds (10 GB of state): the worlds on either side of the seam, and the
+    first and last ones, must equal the same worlds stepped as small batches of their own."""
+    from aquaticgymenv_amd import presets
+    seam = 1 << 28
+    n, steps = seam + 3 * 1024 + 77, 3
+    whole = _make(torch, n, presets.BENCH8, seed=47, auto_reset=mode)
+    whole.reset()
+    whole.rollout(steps, actions="random", keep_all=False)
+    graph = whole.capture_rollout(2, actions="random")          # (a captured rollout: the tick housekeeping of a split launch)
+    graph.launch()
+    torch.cuda.synchronize()
+    for first, m in ((0, 4096), (seam - 2048, 2048 + 3 * 1024 + 77), (1 << 27, 1000)):
+        part = _make(torch, m, presets.BENCH8, seed=47, auto_reset=mode, env_offset=first)
+        part.reset()
+        part.rollout(steps, actions="random", keep_all=False)
+        part.capture_rollout(2, actions="random").launch()
+        torch.cuda.synchronize()
+        assert torch.equal(part.state[:, :m], whole.state[:, first:first + m])
+        assert torch.equal(part.time[:m], whole.time[first:first + m])
+        assert torch.equal(part.reward[:m], whole.reward[first:first + m])
+        assert torch.equal(part.term[:m], whole.term[first:first + m])
+        assert torch.equal(part.done_bits[: m // 64], whole.done_bits[first // 64: first // 64 + m // 64])
+    assert int((whole.time[:n] != 0).sum()) > 0
+    del whole
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mode,env_offset", [(1, 0), (2, 0), (2, 7)], ids=["same_step", "next_step", "next_step_odd_offset"])
 def test_sampled_actions_match_oracle_rollout(torch, oracle, mode, env_offset):
     """40 steps, discrete and continuous.  mode 1: finished worlds are re-seeded in the launch that finished them;
