@@ -107,10 +107,6 @@ def parse(argv=None):
                          "clock (outside every timed interval).  A 20-step graph launched 200 us after a device "
                          "synchronisation runs 0.15-0.3 us per step faster than one launched right behind it, at the price of "
                          "3 %% of wall clock (profiles/r03/k20_settle.txt): off by default")
-    ap.add_argument("--chunk", type=int, default=0,
-                    help="diagnostic: steps per captured graph (default: min(%d, --steps)).  With --chunk W a region of K = m W steps "
-                         "replays the warm-up's own graph m times, so region 0 is not a first launch -- at the price of m graph "
-                         "launches per region (profiles/r04/k20_chunk.txt)" % CHUNK)
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel (separate line)")
     ap.add_argument("--per-world-tables", action="store_true",
                     help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
@@ -604,7 +600,7 @@ def main(argv=None):
                       auto_reset=0 if args.no_auto_reset else args.reset_mode, device=dev)
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    chunk = min(args.chunk if args.chunk > 0 else CHUNK, max(args.steps, 1))
+    chunk = min(CHUNK, max(args.steps, 1))
     if args.continuous:
         actions = torch.rand((CHUNK, 2, env.ld), device=dev, generator=gen) * 0.3 + 0.2
     else:

@@ -2,7 +2,7 @@
 # rocprofv3 evidence of round 4, all on ONE box: the driver's command, the default bench line, the streaming size,
 # continuous actions (kernel-trace stats + FETCH_SIZE / WRITE_SIZE in separate passes), the SQ counters of the benchmarked
 # kernel; then bench lines of the same box without the tracer, the one-rank exchange lines, the N > 1 path rehearsed with two
-# ranks on the one GPU, and the driver's command with the warm-up's own graph granularity (--chunk 5)
+# ranks on the one GPU
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
@@ -17,7 +17,6 @@ python3 tools/make_traffic.py $O n262144_disc_k8=n262144 n16777216_disc_k8=n16m 
 cp profiles/traffic.json $O/traffic.json
 b() { name=$1; shift; python3 bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err || { tail $O/bench_$name.err; exit 1; }; }
 b driver --gpus 1 --steps 20 --warmup 5
-b driver_chunk5 --gpus 1 --steps 20 --warmup 5 --chunk 5 --no-cpu-baseline
 b driver_launch_clock --gpus 1 --steps 20 --warmup 5 --region-clock launch --no-cpu-baseline
 b default --extras --per-world-tables
 b n16m --envs 16777216 --steps 100 --warmup 20 --no-cpu-baseline
