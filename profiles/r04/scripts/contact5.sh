@@ -12,4 +12,4 @@ for n in 2097152 16777216; do
   python3 tools/ab.py --rounds 2 --envs $n --steps 200 cur@2 lateil@2 cur@1 sstile@1 nolate@0 cur@0 > $O/ab_$n.txt 2>&1; echo "== $n"; cat $O/ab_$n.txt
 done
 AQUA_HIP_LIB= python3 tools/r04/fused_ab.py duty0 cur duty0 cur > $O/fused_duty.txt 2>&1; cat $O/fused_duty.txt
-bash tools/r04/tables_coop.sh
+bash profiles/r04/scripts/tables_coop.sh
