@@ -122,6 +122,9 @@ int aqua_pack_obstacles(const double* rows, int K, void* blob_host, size_t blob_
  *                   inside one launch without any synchronisation): -1 - (t & 1) "finished at tick t, awaiting
  *                   restart", -3 - (t & 1) "restarted during tick t, steps from time 0 at tick t + 1".  Ticks must
  *                   advance by one per step in this mode (a marked world otherwise waits one extra step).
+ *   N             : any size the buffers hold.  The step kernels address a world by a 32-bit byte offset from the row
+ *                   pointers of their launch, so the library queues a batch of more than 2^28 worlds as several launches
+ *                   of that many (same stream, same results as one: a world's step depends on its global index only).
  */
 int aqua_step_f32(const AquaParams* p, const void* obst_blob_dev, int K, int64_t N, int64_t env_offset,
                   float* state, int64_t ld, int32_t* time, const void* action, int action_kind,
