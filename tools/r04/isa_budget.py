@@ -6,6 +6,10 @@
     isa_budget.py blocks  <kernel.s>                            one line per basic block: index, label, counts, first comment
     isa_budget.py count   <kernel.s> name=i,j,k-m ...           per named path (lists / ranges of block indices): instructions
                                                                by class and vector-issue cycles
+    isa_budget.py layout  <kernel.s> name=i,j,k-m ...           where the code lies: byte offset and size of every basic block
+                                                               (llvm-mc's encodings of the listing), and per named path the
+                                                               bytes it executes, the span they lie in and the 64-byte
+                                                               instruction-cache lines it touches
 
 Vector-issue cycles of a wavefront on its SIMD: 4 per VALU instruction (64 lanes on 16), 16 for the quarter-rate ones
 (32-bit integer multiplies incl. v_mad_u64_u32, transcendentals v_sin/cos/sqrt/rcp/rsq/exp/log, 64-bit float divides /
@@ -103,6 +107,50 @@ def indices(spec, n):
     return out
 
 
+def block_bytes(path):
+    """-> bytes of code per basic block, same block numbering as parse(): the listing through llvm-mc -show-encoding."""
+    mc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "llvm-mc")
+    out = subprocess.run([mc, "--triple=amdgcn-amd-amdhsa", "--mcpu=gfx950", "-show-encoding", path],
+                         capture_output=True, text=True, check=True).stdout
+    # llvm-mc drops the "; %bb.N:" comments: take the block boundaries from parse() by instruction count instead
+    sizes = []
+    for line in out.splitlines():
+        m = re.search(r"; encoding: \[([^\]]*)\]", line)
+        if m and re.match(r"^\s+[a-z_0-9]+(\s|$)", line):
+            sizes.append(len(m.group(1).split(",")))
+    blocks = parse(path)
+    n_ops = sum(len(b["ops"]) for b in blocks)
+    assert n_ops == len(sizes), "llvm-mc saw %d instructions, the listing holds %d" % (len(sizes), n_ops)
+    per_block, at = [], 0
+    for b in blocks:
+        per_block.append(sum(sizes[at:at + len(b["ops"])]))
+        at += len(b["ops"])
+    return blocks, per_block
+
+
+def layout(path, specs):
+    blocks, size = block_bytes(path)
+    start = [0]
+    for s in size:
+        start.append(start[-1] + s)
+    print("kernel: %d basic blocks, %d bytes of code = %d instruction-cache lines of 64 B" % (len(blocks), start[-1], (start[-1] + 63) // 64))
+    for spec in specs:
+        name, idx = spec.split("=")
+        ids = sorted(set(indices(idx, len(blocks))))
+        lines = set()
+        for i in ids:
+            if size[i]:
+                lines.update(range(start[i] // 64, (start[i] + size[i] - 1) // 64 + 1))
+        executed = sum(size[i] for i in ids)
+        lo, hi = min(start[i] for i in ids), max(start[i] + size[i] for i in ids)
+        print("%-36s executes %6d B in [%6d, %6d) = %5.1f %% of that span; %4d cache lines touched (%d B); "
+              "skipped inside the span: %d B" % (name, executed, lo, hi, 100.0 * executed / max(hi - lo, 1), len(lines), 64 * len(lines),
+                                                  hi - lo - executed))
+    print()
+    for i, b in enumerate(blocks):
+        print("%3d %-10s at %6d  %5d B" % (i, b["label"], start[i], size[i]))
+
+
 def main(argv):
     if len(argv) < 2:
         sys.exit(__doc__)
@@ -121,6 +169,9 @@ def main(argv):
                 sys.stdout.write(line)
                 if ".end_amdhsa_kernel" in line:
                     break
+        return
+    if argv[0] == "layout":
+        layout(argv[1], argv[2:])
         return
     blocks = parse(argv[1])
     if argv[0] == "blocks":
