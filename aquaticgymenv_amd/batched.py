@@ -622,6 +622,28 @@ class BatchedAqua(object):
         self._device_tick = -1            # graphs captured on this batch read the tick base from the device: refresh it
         return self
 
+    def snapshot(self):
+        """The batch as it is now, kept ON THE DEVICE (clones of the state rows, time markers, last outputs and counters):
+        restore() puts it back bit for bit.  What state_dict() is for a checkpoint on disk, this is for a look-ahead that
+        is taken back (a planner's trial rollouts, bench.py's untimed first replay of a graph)."""
+        snap = {name: getattr(self, name).clone() for name in ("state", "time", "reward", "term", "done_bits")}
+        if self.obs_norm_buf is not None:
+            snap["obs_norm_buf"] = self.obs_norm_buf.clone()
+        if self.clipped_actions is not None:
+            snap["clipped_actions"] = self.clipped_actions.clone()
+        snap["_tick"], snap["_resets"] = self._tick, self._resets
+        return snap
+
+    def restore(self, snap):
+        """Back to a snapshot() of THIS batch (device-to-device copies on the current stream, no synchronisation)."""
+        for name in ("state", "time", "reward", "term", "done_bits", "obs_norm_buf", "clipped_actions"):
+            if name in snap:
+                getattr(self, name).copy_(snap[name])
+        self._tick, self._resets = snap["_tick"], snap["_resets"]
+        self._device_tick = -1            # graphs captured on this batch read the tick base from the device: refresh it
+        self._sync_device_tick()
+        return self
+
     # ------------------------------------------------------------------ helpers
     def done_mask(self):
         """uint8 [N] done flags unpacked from the ballot words (for checks; step() already returns term)."""

@@ -102,6 +102,10 @@ def parse(argv=None):
                          "them.  Measured on one box at --steps 20 (profiles/r03/region_clock.txt): 5.1-5.4 us per step by the "
                          "attached events against 5.5 by the stream events around a graph -- and 13-17 %% less throughput by wall "
                          "clock, noisier regions (the host queues every launch): not the default" % CHUNK)
+    ap.add_argument("--first-replay", choices=("upload", "rollback"), default="rollback",
+                    help="graphs of the timed region that the warm-up budget cannot replay (warmup < steps): 'upload' = "
+                         "hipGraphUpload ahead of region 0; 'rollback' = ALSO one untimed replay whose effect on the batch is "
+                         "undone (BatchedAqua.snapshot / restore), so that region 0 is not a graph's first launch")
     ap.add_argument("--settle-us", type=float, default=0.0,
                     help="diagnostic: host pause between the barrier that closes a region and the start of the next region's "
                          "clock (outside every timed interval).  A 20-step graph launched 200 us after a device "
@@ -200,6 +204,27 @@ class StepRunner(object):
                 todo.append(seg[:3])
         for key in todo:
             self.graphs[key].upload()
+        return len(todo)
+
+    def replay_unplayed_and_roll_back(self, timed_steps, played):
+        """Replay, once and untimed, the graphs of a region of timed_steps steps that none of the `played` run lengths
+        replays, then put the batch back where it was (BatchedAqua.snapshot / restore: bit for bit, tick and
+        restart markers included): the timed regions start from the state the warm-up left, and none of them is the
+        first launch of its graph.  -> how many graphs were replayed"""
+        if not self.use_graph:
+            return 0
+        seen = set(seg[:3] for n in played for seg in self.plan(n))
+        todo = []
+        for seg in self.plan(timed_steps):
+            if seg[:3] not in seen:
+                seen.add(seg[:3])
+                todo.append(seg[:3])
+        if not todo:
+            return 0
+        saved = self.env.snapshot()
+        for key in todo:
+            self.graphs[key].launch()
+        self.env.restore(saved)                          # (refreshes the device's tick base here, not inside region 0)
         return len(todo)
 
     def region_is_timed_graph(self, n_steps):
@@ -664,8 +689,14 @@ def main(argv=None):
         runner.run(w)
         drain()
     drain()
-    rendezvous()
     x_before = float(env.state[0, :n].double().sum().item())
+    if args.first_replay == "rollback" and runner.use_graph and not by_launch:
+        rolled_back = runner.replay_unplayed_and_roll_back(args.steps, warm)
+        torch.cuda.synchronize()
+        if rolled_back:
+            first_replay = ("one untimed replay rolled back to the state after the warm-up (%d graph%s the warm-up does not replay)"
+                            % (rolled_back, "s" * (rolled_back != 1)))
+    rendezvous()
     walls, events, launch_ev, node_ms, segs = [], [], [], [], []
     for _ in range(args.regions):
         # HIP events on the stream the step kernels are launched on, around the region's launches (the contract's

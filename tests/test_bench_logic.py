@@ -37,6 +37,14 @@ class StubEnv(object):
         self._tick += steps
         self.calls.append((how, steps))
 
+    def snapshot(self):
+        self.calls.append(("snapshot", self._tick))
+        return {"_tick": self._tick}
+
+    def restore(self, snap):
+        self.calls.append(("restore", snap["_tick"]))
+        self._tick = snap["_tick"]
+
     def capture_rollout(self, steps, actions=None, keep_all=False, done_history=None, timing=False):
         assert steps >= 1
         self.captured.append(steps)
@@ -308,6 +316,12 @@ def test_warmup_replays_the_timed_graphs_or_uploads_them():
         r.prepare(w)
     r.prepare(20)
     assert r.upload_unplayed(20, warm) == 1 and r.graphs[(0, 0, 20)].uploads == 1 and r.graphs[(0, 0, 5)].uploads == 0
+    # ... or replayed once, untimed, and the batch put back where the warm-up left it (--first-replay rollback)
+    r.run(5)
+    assert env._tick == 5 and r.steps_run == 5
+    assert r.replay_unplayed_and_roll_back(20, warm) == 1
+    assert env._tick == 5 and r.steps_run == 5 and env.calls[-3:] == [("snapshot", 5), ("graph", 20), ("restore", 5)]
+    assert r.replay_unplayed_and_roll_back(5, warm) == 0 and env.calls[-1] == ("restore", 5)      # nothing unplayed: nothing touched
     # defaults: 2 of the 2000-step region's 10 graphs are the warm-up's own
     env, hist = StubEnv(), _hist()
     r = bench.StepRunner(env, None, hist, None, use_graph=True, chunk=bench.CHUNK)

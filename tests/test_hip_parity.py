@@ -1464,6 +1464,41 @@ def test_checkpoint_resumes_bit_for_bit(torch, mode):
         _make(torch, n, presets.NONE, seed=11, auto_reset=mode).load_state_dict(ckpt)
 
 
+@pytest.mark.parametrize("mode", ["next_step", "same_step", False])
+def test_snapshot_taken_back_on_the_device(torch, mode):
+    """snapshot() after 30 steps, a 20-step look-ahead (a captured graph), restore(): the 50 steps that follow equal the
+    50 steps of a batch that never looked ahead -- eagerly and through the graph captured BEFORE the snapshot, bit for bit"""
+    from aquaticgymenv_amd import presets
+    n = 5000
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    acts = torch.randint(0, 3, (80, 5120), device="cuda:0", generator=g, dtype=torch.int64).to(torch.uint8)
+    plain = _make(torch, n, presets.BENCH8, seed=11, auto_reset=mode)
+    plain.reset()
+    plain.rollout(30, actions=acts[:30, :plain.ld].contiguous(), keep_all=False)
+    rew1, term1 = plain.rollout(50, actions=acts[30:, :plain.ld].contiguous(), keep_all=True)
+    want = (rew1[:, :n].clone(), term1[:, :n].clone(), plain.state[:, :n].clone(), plain.time[:n].clone(), plain.done_bits.clone())
+    for graph in (False, True):
+        env = _make(torch, n, presets.BENCH8, seed=11, auto_reset=mode)
+        env.reset()
+        a = acts[:, :env.ld].contiguous()
+        ahead = env.capture_rollout(20, actions=a[:20], keep_all=False)
+        gr = env.capture_rollout(50, actions=a[30:], keep_all=True) if graph else None
+        env.rollout(30, actions=a[:30], keep_all=False)
+        snap = env.snapshot()
+        assert snap["state"].device.type == "cuda" and snap["_tick"] == 30
+        ahead.launch()
+        ahead.launch()
+        assert env._tick == 70
+        env.restore(snap)
+        assert env._tick == 30
+        rew2, term2 = gr.launch() if graph else env.rollout(50, actions=a[30:], keep_all=True)
+        torch.cuda.synchronize()
+        got = (rew2[:, :n], term2[:, :n], env.state[:, :n], env.time[:n], env.done_bits)
+        for name, x, y in zip(("reward", "term", "state", "time", "done_bits"), want, got):
+            assert torch.equal(x, y), "%s differs after the look-ahead was taken back (graph=%s)" % (name, graph)
+        assert env._tick == 80
+
+
 def test_clipped_action_counter(torch):
     """aqua.py:145-150 prints and clips a continuous action outside [0.2, 0.5]; the batched path clips in the kernel and --
     with count_clipped=True -- counts the worlds it clipped for"""
