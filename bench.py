@@ -106,6 +106,8 @@ def parse(argv=None):
                     help="graphs of the timed region that the warm-up budget cannot replay (warmup < steps): 'upload' = "
                          "hipGraphUpload ahead of region 0; 'rollback' = ALSO one untimed replay whose effect on the batch is "
                          "undone (BatchedAqua.snapshot / restore), so that region 0 is not a graph's first launch")
+    ap.add_argument("--ramp-replays", type=int, default=1,
+                    help="--first-replay rollback: how many times the untimed replay is repeated before it is taken back")
     ap.add_argument("--settle-us", type=float, default=0.0,
                     help="diagnostic: host pause between the barrier that closes a region and the start of the next region's "
                          "clock (outside every timed interval).  A 20-step graph launched 200 us after a device "
@@ -206,7 +208,7 @@ class StepRunner(object):
             self.graphs[key].upload()
         return len(todo)
 
-    def replay_unplayed_and_roll_back(self, timed_steps, played):
+    def replay_unplayed_and_roll_back(self, timed_steps, played, repeats=1):
         """Replay, once and untimed, the graphs of a region of timed_steps steps that none of the `played` run lengths
         replays, then put the batch back where it was (BatchedAqua.snapshot / restore: bit for bit, tick and
         restart markers included): the timed regions start from the state the warm-up left, and none of them is the
@@ -222,8 +224,9 @@ class StepRunner(object):
         if not todo:
             return 0
         saved = self.env.snapshot()
-        for key in todo:
-            self.graphs[key].launch()
+        for _ in range(max(1, repeats)):
+            for key in todo:
+                self.graphs[key].launch()
         self.env.restore(saved)                          # (refreshes the device's tick base here, not inside region 0)
         return len(todo)
 
@@ -691,7 +694,7 @@ def main(argv=None):
     drain()
     x_before = float(env.state[0, :n].double().sum().item())
     if args.first_replay == "rollback" and runner.use_graph and not by_launch:
-        rolled_back = runner.replay_unplayed_and_roll_back(args.steps, warm)
+        rolled_back = runner.replay_unplayed_and_roll_back(args.steps, warm, repeats=args.ramp_replays)
         torch.cuda.synchronize()
         if rolled_back:
             first_replay = ("one untimed replay rolled back to the state after the warm-up (%d graph%s the warm-up does not replay)"
