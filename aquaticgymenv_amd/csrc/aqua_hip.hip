@@ -814,6 +814,9 @@ __device__ __forceinline__ void serve_reseed(const ReseedTicket& tk, const A& a,
     // that depended on the tick alone put the re-seeding passes of all of a CU's blocks on one SIMD (fused rollout, next-step
     // restarts: 4.38 -> 4.05 us per step, profiles/r04/fused_duty/)
     if (tk.n == 0 || wave != static_cast<int>((static_cast<uint32_t>(tick) + blockIdx.x) & (WAVES - 1))) return;
+#ifdef AQUA_FUSED_NOSERVE                    // (timing experiment: the protocol without the re-seeding pass)
+    return;
+#endif
     uint32_t first[WAVES + 1];
     first[0] = 0;
 #pragma unroll

@@ -15,7 +15,7 @@ from aquaticgymenv_amd.batched import BatchedAqua
 n, T = 262144, 500
 out = []
 for tables in (False, True):
-    for mode in ("next_step", "same_step"):
+    for mode in ("next_step", "same_step") + ((False,) if __import__("os").environ.get("AQUA_FUSED_AB_NO_RESTART") else ()):
         obst = presets.BENCH8
         if tables:
             rng = np.random.RandomState(7)
@@ -32,7 +32,7 @@ for tables in (False, True):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); env.rollout(T, actions=acts, fused=True, keep_all=False); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / T)
-        out.append("%%s/%%s %%.3f" %% ("tables" if tables else "shared", mode, best))
+        out.append("%%s/%%s %%.3f" %% ("tables" if tables else "shared", mode or "no_restart", best))
         del env
 print("FUSED " + "  ".join(out))
 '''
