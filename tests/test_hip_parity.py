@@ -777,7 +777,26 @@ def test_long_per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mo
     bit-exact, restarted worlds bit for bit, floats within 1e-5), and the fused rollout -- its LDS tile of 16 rows x 256
     worlds, 32 x 128 or 64 x 64 -- against those launches, bit for bit, eagerly and as a replayed graph"""
     n, T = (9000 + 5, 24) if K <= 16 else (2300 + 5, 24)     # (ragged against every tile width: 256, 128, 64)
-    rng = np.random.RandomState(100 + K)
+    restarted = _per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mode, n, T, 100 + K)
+    if mode:
+        assert restarted > n // 20
+
+
+FUZZ_TABLE_CASES = int(__import__("os").environ.get("AQUA_FUZZ_TABLE_CASES", "6"))
+
+
+@pytest.mark.parametrize("case", range(FUZZ_TABLE_CASES))
+def test_random_per_world_tables_against_the_oracle_and_fused(torch, oracle, case):
+    """the same comparison for seeded random table lengths (1 to 64 rows: every kernel instantiation and every row count
+    inside it), batch sizes and restart modes.  AQUA_FUZZ_TABLE_CASES=N runs N of them (default 6)."""
+    rng = np.random.RandomState(9000 + case)
+    K = int(rng.randint(1, 65)) if rng.randint(0, 2) else int(rng.randint(1, 17))
+    n = int(rng.choice([1, 63, 65, 129, 257, int(rng.randint(300, 3000))]))
+    _per_world_tables_against_the_oracle_and_fused(torch, oracle, K, int(rng.randint(0, 3)), n, int(rng.randint(8, 25)), 9000 + case)
+
+
+def _per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mode, n, T, seed):
+    rng = np.random.RandomState(seed)
     tables = _random_tables(rng, n, K)
     acts = torch.as_tensor(rng.randint(0, 3, (T, n)).astype(np.uint8)).cuda()
     env = _make(torch, n, tables, seed=77, auto_reset=mode, env_offset=64)
@@ -814,11 +833,10 @@ def test_long_per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mo
             o_rew = o_rew.astype(np.float32)
         assert np.array_equal(term.cpu().numpy(), o_term)
         assert np.max(np.abs(reward.cpu().numpy() - o_rew)) <= TOL
-        assert np.max(np.abs(k_state[0:2, moved] - st[0:2, moved])) <= TOL
-        assert np.max(angle_diff(k_state[2, moved], st[2, moved])) <= TOL
-        assert np.max(np.abs(k_state[5:7, moved] - st[5:7, moved])) <= 1e-7
-    if mode:
-        assert restarted > n // 20
+        if moved.any():
+            assert np.max(np.abs(k_state[0:2, moved] - st[0:2, moved])) <= TOL
+            assert np.max(angle_diff(k_state[2, moved], st[2, moved])) <= TOL
+            assert np.max(np.abs(k_state[5:7, moved] - st[5:7, moved])) <= 1e-7
     fused, fgraph = (_make(torch, n, tables, seed=77, auto_reset=mode, env_offset=64) for _ in range(2))
     fused.reset(); fgraph.reset()
     r, c = fused.rollout(T, actions=acts, fused=True, keep_all=True)
@@ -830,6 +848,7 @@ def test_long_per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mo
         assert torch.equal(r2[t, :n], want_r[t]) and torch.equal(c2[t, :n], want_t[t])
     for other in (fused, fgraph):
         assert torch.equal(other.state[:, :n], env.state[:, :n]) and torch.equal(other.time[:n], env.time[:n])
+    return restarted
 
 
 def test_per_world_next_step_equals_the_shared_table_kernel(torch):
