@@ -14,7 +14,7 @@ obstacles, waves on, Philox noise, auto-reset on.  N > 1: the same batch PER GPU
 range-partitioned global world indices, the done mask exchanged on side streams (peer copies through hipIpcMemHandle
 when the ranks can map each other's buffers, else RCCL's all-gather).
 
-Protocol: W untimed warm-up steps, then REGIONS (5) timed regions of EXACTLY K
+Protocol: W untimed warm-up steps, then timed regions (max(5, ceil(2000 / K)) of them) of EXACTLY K
 steps each, every region bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's clock
 stops when ITS queue has drained, steps and done-mask gathers; the barrier follows) and reduced
 with MAX over the ranks; the MEDIAN region is the one reported (`value`, `ms_per_step`; all five are
@@ -44,7 +44,9 @@ HBM_PEAK_GBPS = 8000.0
 HBM_COPY_GBPS = 6290.0   # measured float4 copy (MI355X_MICROARCH.md chip table): SURVEY.md 8(d) asks for this fraction too
 CHUNK = 100          # steps per captured HIP graph (at most)
 GATHER_EVERY = 5     # chunks per done-mask block: one [GATHER_EVERY * CHUNK][words] all-gather per block (N > 1)
-REGIONS = 5          # timed regions; the median is reported
+REGIONS = 5          # timed regions at least; the median is reported
+MIN_TIMED_STEPS = 2000   # ... and at least this many timed steps in all (one default region's worth): see regions_for()
+MAX_REGIONS = 400
 
 
 def parse(argv=None):
@@ -60,7 +62,9 @@ def parse(argv=None):
                     help="restart of finished worlds: 2 = during the next step (default, fastest), 1 = inside the same launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH CPU baseline leg")
-    ap.add_argument("--regions", type=int, default=REGIONS, help="timed regions of --steps steps each (median reported)")
+    ap.add_argument("--regions", type=int, default=None,
+                    help="timed regions of --steps steps each (median reported); default: max(%d, ceil(%d / steps)), see regions_for()"
+                         % (REGIONS, MIN_TIMED_STEPS))
     ap.add_argument("--eager", action="store_true", help="no HIP graph: one C-side launch loop per chunk")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the done-mask exchange (side streams) even on one GPU: rehearsal of the N > 1 path")
@@ -121,9 +125,23 @@ def parse(argv=None):
         ap.error("--steps must be >= 1")
     if args.warmup < 0:
         ap.error("--warmup must be >= 0")
+    if args.regions is None:
+        args.regions, args.regions_rule = regions_for(args.steps), "max(%d, ceil(%d / steps))" % (REGIONS, MIN_TIMED_STEPS)
+    else:
+        args.regions_rule = "--regions"
     if args.regions < 1:
         ap.error("--regions must be >= 1")
     return args
+
+
+def regions_for(steps):
+    """How many timed regions of `steps` steps: five at least, and as many as it takes to time MIN_TIMED_STEPS steps in all.
+    Five regions of 20 steps are 0.6 ms of GPU work on a GPU that has been busy for less than a millisecond since the process
+    started: they read 0.3-0.5 us per step above what the same command reads a few milliseconds later (60 regions: the first 14
+    at 5.1-5.5 us, the rest at 4.7-5.1: profiles/FLOOR.md) -- a sample too short for the median to mean anything.  Every
+    region is still exactly `steps` steps between its own brackets and is listed; the first five are also reported on their
+    own (roofline.first_regions)."""
+    return min(MAX_REGIONS, max(REGIONS, -(-MIN_TIMED_STEPS // max(steps, 1))))
 
 
 # ------------------------------------------------------------------ the step queue (host logic; tests/test_bench_logic.py)
@@ -756,6 +774,8 @@ def main(argv=None):
         # packets of their own and read 12-14 us more per region than first kernel start -> last kernel end)
         launch_s = statistics.median(launch_ev if by_launch else events) * 1e-3 / args.steps
         achieved = a_bytes * n / launch_s / 1e9
+        first_s = statistics.median((launch_ev if by_launch else events)[:REGIONS]) * 1e-3 / args.steps
+        first_wall = statistics.median(walls[:REGIONS])
         traffic, traffic_src = committed_traffic(n, args)
         # `value` counts every world of the batch in every step.  With next-step restarts a world that finished at tick t
         # does not step during tick t + 1 (it is re-seeded and reports reward 0, term 0): those ticks are the episodes that
@@ -768,7 +788,8 @@ def main(argv=None):
             "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "regions": args.regions, "regions_ms": [w * 1e3 for w in walls], "region_reported": "median",
+            "regions": args.regions, "regions_rule": args.regions_rule, "regions_ms": [w * 1e3 for w in walls],
+            "region_reported": "median",
             "config": {"workload": "batch %d worlds/GPU, %s actions, %s, waves on, auto-reset (%s), %s of <= %d steps"
                        % (n, "continuous f32x2" if args.continuous else "discrete u8",
                           "no obstacles" if args.no_obstacles else "4 circle + 4 rect obstacles",
@@ -789,6 +810,11 @@ def main(argv=None):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
                          "issue_bound_us": issue_us, "issue_bound_source": issue_src,
+                         "first_regions": {"n": min(REGIONS, args.regions), "launch_us": first_s * 1e6,
+                                           "frac": a_bytes * n / first_s / 1e9 / HBM_PEAK_GBPS,
+                                           "ms_per_step": first_wall * 1e3 / args.steps,
+                                           "value": world * n * args.steps / first_wall,
+                                           "what": "the same figures from the median of the FIRST %d regions alone" % min(REGIONS, args.regions)},
                          "launch_us_regions": [e * 1e3 / args.steps for e in (launch_ev if by_launch else events)],
                          "launch_us_events": "launch" if by_launch else "stream",
                          "launch_us_stream_events_regions": [e * 1e3 / args.steps for e in events],

@@ -43,14 +43,18 @@ def _check_line(r, steps, warmup, n_gpus=1, envs=262144, timings_mean_something=
     assert r["config"]["baseline_config"] == "configs[2]" and str(envs) in r["config"]["workload"]
     assert r["config"]["ranks_seen"] == n_gpus and len(r["config"]["devices"]) == n_gpus
     assert r["config"]["launch"] == ("eager" if clock == "launch" else "hipGraph")
-    assert len(r["regions_ms"]) == r["regions"] == 5
-    assert sorted(r["regions_ms"])[2] == pytest.approx(r["ms_per_step"] * steps)
+    regions = max(5, -(-2000 // steps))              # bench.regions_for(): five at least, 2 000 timed steps at least
+    assert len(r["regions_ms"]) == r["regions"] == regions and r["regions_rule"].startswith("max(5")
+    assert sorted(r["regions_ms"])[(regions - 1) // 2] == pytest.approx(r["ms_per_step"] * steps)
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"])
     assert roof["achieved"] == pytest.approx(62 * envs / (roof["launch_us"] * 1e-6) / 1e9)
-    assert roof["launch_us_events"] == clock and len(roof["launch_us_regions"]) == 5
-    assert len(roof["launch_us_stream_events_regions"]) == 5 and 0.0 < roof["frac_by_stream_events"] < 1.0
+    assert roof["launch_us_events"] == clock and len(roof["launch_us_regions"]) == regions
+    assert len(roof["launch_us_stream_events_regions"]) == regions and 0.0 < roof["frac_by_stream_events"] < 1.0
+    first = roof["first_regions"]                      # the first five regions on their own
+    assert first["n"] == 5 and first["frac"] == pytest.approx(62 * envs / (first["launch_us"] * 1e-6) / 1e9 / 8000.0)
+    assert first["launch_us"] == pytest.approx(sorted(roof["launch_us_regions"][:5])[2])
     if clock == "launch" and timings_mean_something:
         # first kernel start -> last kernel end lies INSIDE the two stream events recorded around the same launches
         assert all(a <= b * 1.001 for a, b in zip(roof["launch_us_regions"], roof["launch_us_stream_events_regions"]))
@@ -59,7 +63,7 @@ def _check_line(r, steps, warmup, n_gpus=1, envs=262144, timings_mean_something=
         assert roof["launch_us_regions"] == roof["launch_us_stream_events_regions"]
     assert (0.05 if timings_mean_something else 0.0) < roof["frac"] < 1.0
     assert "traffic" in roof and "traffic_source" in roof
-    assert r["sanity"]["steps_queued"] == warmup + 5 * steps
+    assert r["sanity"]["steps_queued"] == warmup + regions * steps
     assert r["sanity"]["episodes_ended_last_region"] > 0
     # what `value` counts: every world in every step; the restart ticks of the next-step mode are reported beside it
     frac = r["sanity"]["restart_ticks_fraction"]
@@ -84,7 +88,7 @@ def test_bench_with_the_drivers_flags_in_a_child_process():
 def test_bench_odd_step_counts_in_a_child_process():
     """one step without warm-up, and a count that needs full chunks + a remainder"""
     r = _run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
-    assert r["steps"] == 1 and r["sanity"]["steps_queued"] == 5
+    assert r["steps"] == 1 and r["regions"] == 400 and r["sanity"]["steps_queued"] == 400      # (bench.MAX_REGIONS one-step regions)
     r = _run([sys.executable, "bench.py", "--steps", "230", "--warmup", "7", "--no-cpu-baseline"])
     _check_line(r, 230, 7)
 
@@ -97,13 +101,13 @@ def test_bench_diagnostic_flags_in_a_child_process():
               "--copy-engine", "dma", "--graph-node-events", "--settle-us", "100"])
     _check_line(r, 20, 5)
     nodes = r["roofline"]["launch_us_graph_nodes_regions"]
-    assert len(nodes) == 5 and all(v and v > 1.0 for v in nodes)
+    assert len(nodes) == 100 and all(v and v > 1.0 for v in nodes)
     assert r["config"]["done_mask_exchange_kind"] == "ipc" and r["config"]["done_mask_copy_engine"] == "dma"
     assert r["sanity"]["done_mask_exchange_last_block"]["own_block_intact"] is True
     r = _run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--region-clock", "launch"])
     _check_line(r, 20, 5, clock="launch")               # the events attached to the region's first and last launch
     r = _run([sys.executable, "bench.py", "--steps", "30", "--warmup", "3", "--no-cpu-baseline", "--eager"])
-    assert r["config"]["launch"] == "eager" and r["steps"] == 30 and r["sanity"]["steps_queued"] == 3 + 5 * 30
+    assert r["config"]["launch"] == "eager" and r["steps"] == 30 and r["sanity"]["steps_queued"] == 3 + 67 * 30
 
 
 @pytest.mark.gpu

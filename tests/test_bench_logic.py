@@ -175,7 +175,12 @@ def test_median_pick():
 
 def test_argument_checks():
     assert bench.parse(["--steps", "20", "--warmup", "5"]).steps == 20
-    assert bench.parse([]).regions == bench.REGIONS
+    assert bench.parse([]).regions == bench.REGIONS and bench.parse([]).regions_rule.startswith("max(5")
+    # five regions at least, and at least one default region's worth of timed steps in all
+    assert bench.parse(["--steps", "20", "--warmup", "5"]).regions == 100 and bench.regions_for(1) == bench.MAX_REGIONS
+    assert [bench.regions_for(k) for k in (20, 100, 399, 400, 401, 2000, 100000)] == [100, 20, 6, 5, 5, 5, 5]
+    explicit = bench.parse(["--steps", "20", "--regions", "7"])
+    assert explicit.regions == 7 and explicit.regions_rule == "--regions"
     for bad in (["--steps", "0"], ["--warmup", "-1"], ["--regions", "0"], ["--region-clock", "auto"]):
         with pytest.raises(SystemExit):
             bench.parse(bad)
