@@ -17,8 +17,8 @@ when the ranks can map each other's buffers, else RCCL's all-gather).
 Protocol: W untimed warm-up steps, then timed regions (max(5, ceil(2000 / K)) of them) of EXACTLY K
 steps each, every region bracketed by barrier + torch.cuda.synchronize() on both sides (a rank's clock
 stops when ITS queue has drained, steps and done-mask gathers; the barrier follows) and reduced
-with MAX over the ranks; the MEDIAN region is the one reported (`value`, `ms_per_step`; all five are
-listed under `regions_ms`).  Steps are queued as replays of captured HIP graphs of min(CHUNK, K) steps
+with MAX over the ranks; the MEDIAN region is the one reported (`value`, `ms_per_step`; all of them are
+listed under `regions_ms`, the first five are also reported on their own: `roofline.first_regions`).  Steps are queued as replays of captured HIP graphs of min(CHUNK, K) steps
 (+ one graph for the remainder), so that any K >= 1 and W >= 0 runs the same way.  Inputs are resident
 in HBM before the timed regions.  `roofline` comes from HIP events recorded on the launch stream around each region's
 launches.  Rank 0 prints ONE JSON line.
