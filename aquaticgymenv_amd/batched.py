@@ -88,12 +88,20 @@ class RolloutGraph(object):
         self.term = term
         self._events = events             # (start, stop) AquaEvent handles recorded as nodes of the graph, or None
         self._clip_view = None            # continuous thrusts [T][2][N] whose clipped worlds every launch() counts
+        self._launch = _capi.lib.aqua_graph_launch
 
-    def launch(self):
+    def launch(self, stream=None):
+        """Replay the graph.  stream: the HIP stream as a ctypes.c_void_p marshalled once by a caller that replays in a tight
+        loop (bench.py: ~3 us of host time per replay sit between an event recorded ahead of the launch and the launch
+        itself, and on an idle stream they count: profiles/r04/launch_gap/); default: torch's current stream."""
         env = self._env
-        env._sync_device_tick()
-        env._count_clipped(self._clip_view)            # (count_clipped=True: a replay steps with the buffer's CURRENT content)
-        _capi.check(_capi.lib.aqua_graph_launch(self._handle, env._stream()), "aqua_graph_launch")
+        if env._device_tick != env._tick:
+            env._sync_device_tick()
+        if self._clip_view is not None:
+            env._count_clipped(self._clip_view)        # (count_clipped=True: a replay steps with the buffer's CURRENT content)
+        rc = self._launch(self._handle, stream if stream is not None else env._stream())
+        if rc:
+            _capi.check(rc, "aqua_graph_launch")
         env._tick += self.steps
         env._device_tick += self.steps
         return self.reward, self.term

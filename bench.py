@@ -178,10 +178,16 @@ class StepRunner(object):
         self.launch_events = launch_events               # a LaunchEvents: one-block regions of run(clock=True) carry it
         self.block_rows = int(hist[0].shape[0])
         self.graphs = {}
+        self.stream_handle = None                        # set_stream(): the launch stream, marshalled once for graph.launch()
         self._plans = {}
         self.timed = set()
         self.timing_error = None
         self.steps_run = 0
+
+    def set_stream(self, torch_stream):
+        """the stream every launch of run() goes to (it must be torch's current stream while run() is called)"""
+        import ctypes
+        self.stream_handle = ctypes.c_void_p(torch_stream.cuda_stream)
 
     def plan(self, n_steps):
         segs = self._plans.get(n_steps)                  # (a 100-microsecond region should not pay for re-planning itself)
@@ -289,17 +295,22 @@ class StepRunner(object):
         self.launch_events attached to its first and last launch"""
         segs = self.plan(n_steps)
         by_launch = clock and self.clocked_by_launch_events(n_steps)
+        handle = self.stream_handle
         for i, (buf, row0, s, gather_after) in enumerate(segs):
             if self.exchange is not None and row0 == 0:
                 self.exchange.wait_source(buf)
+            # (everything that can be looked up ahead of the region's first event is: on an idle stream the event is stamped
+            # at once and the host time until the launch counts as the region's, profiles/r04/launch_gap/)
+            graph = (self.graphs[("clocked", buf, row0, s) if by_launch else (buf, row0, s)]
+                     if (by_launch or self.use_graph) else None)
             if before_first_launch is not None and i == 0:
                 before_first_launch()
-            if by_launch:
-                self.graphs[("clocked", buf, row0, s)].launch()
-            elif self.use_graph:
-                self.graphs[(buf, row0, s)].launch()
-            else:
+            if graph is None:
                 self.env.rollout(s, actions=self.actions, keep_all=False, done_history=self.hist[buf][row0:row0 + s])
+            elif by_launch or handle is None:
+                graph.launch()
+            else:
+                graph.launch(handle)
             if after_last_launch is not None and i == len(segs) - 1:
                 after_last_launch()
             if self.exchange is not None and gather_after:
@@ -672,6 +683,7 @@ def main(argv=None):
         watchdog.cancel()
     runner = StepRunner(env, actions, hist, exchange, use_graph=not args.eager, chunk=chunk,
                         launch_events=LaunchEvents() if args.region_clock == "launch" else None)
+    runner.set_stream(launch_stream)                     # (torch's current stream since set_stream() above)
     by_launch = runner.clocked_by_launch_events(args.steps)
     if args.region_clock == "launch" and not by_launch:
         raise SystemExit("--region-clock launch: a region of %d steps is more than one block of %d" % (args.steps, chunk))

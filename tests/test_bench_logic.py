@@ -13,8 +13,9 @@ class StubGraph(object):
         self.env, self.steps, self.done_history, self.how = env, steps, done_history, how
         self.launches = self.uploads = 0
 
-    def launch(self):
+    def launch(self, stream=None):
         self.launches += 1
+        self.streams = getattr(self, "streams", []) + [stream]
         self.env._do(self.steps, self.done_history, self.how)
 
     def upload(self):
@@ -304,6 +305,19 @@ def test_run_ranks_relays_the_line_and_kills_what_outlives_its_deadline():
     assert timed_out and line is None and status != 0 and time.time() - t0 < 30
     status, line, timed_out = bench.run_ranks([sys.executable, "-c", "import sys; sys.exit(3)"], dict(__import__("os").environ), 30, err=err)
     assert (status, line, timed_out) == (3, None, False)
+
+
+def test_graph_launches_get_the_marshalled_stream():
+    """the runner looks its graph up ahead of the region's first event and hands launch() the stream it marshalled once"""
+    env, hist = StubEnv(), _hist(20)
+    r = bench.StepRunner(env, None, hist, None, use_graph=True, chunk=20)
+    r.prepare(20)
+    order = []
+    r.run(20, before_first_launch=lambda: order.append("event"), after_last_launch=lambda: order.append("event"))
+    assert r.graphs[(0, 0, 20)].streams == [None] and order == ["event", "event"]
+    r.stream_handle = "the stream"
+    r.run(20)
+    assert r.graphs[(0, 0, 20)].streams == [None, "the stream"] and env._tick == 40
 
 
 def test_warmup_replays_the_timed_graphs_or_uploads_them():
