@@ -488,9 +488,10 @@ def test_obstacle_table_shapes_match_oracle_rollout(torch, oracle, mix, mode):
 
 
 FUZZ_CASES = int(__import__("os").environ.get("AQUA_FUZZ_CASES", "12"))
+FUZZ_FIRST = int(__import__("os").environ.get("AQUA_FUZZ_FIRST", "0"))      # (a longer campaign continues where the last one stopped)
 
 
-@pytest.mark.parametrize("case", range(FUZZ_CASES))
+@pytest.mark.parametrize("case", range(FUZZ_FIRST, FUZZ_FIRST + FUZZ_CASES))
 def test_random_configurations_against_the_oracle(torch, oracle, case):
     """Seeded random configurations -- obstacle mix (0-20 rows: every quick-table shape and the row loops), batch size
     (1 to a few thousand, ragged), action space, restart mode, world offset (even, odd, beyond 2^32), sampled or buffered
@@ -785,7 +786,7 @@ def test_long_per_world_tables_against_the_oracle_and_fused(torch, oracle, K, mo
 FUZZ_TABLE_CASES = int(__import__("os").environ.get("AQUA_FUZZ_TABLE_CASES", "6"))
 
 
-@pytest.mark.parametrize("case", range(FUZZ_TABLE_CASES))
+@pytest.mark.parametrize("case", range(FUZZ_FIRST, FUZZ_FIRST + FUZZ_TABLE_CASES))
 def test_random_per_world_tables_against_the_oracle_and_fused(torch, oracle, case):
     """the same comparison for seeded random table lengths (1 to 64 rows: every kernel instantiation and every row count
     inside it), batch sizes and restart modes.  AQUA_FUZZ_TABLE_CASES=N runs N of them (default 6)."""
