@@ -569,7 +569,11 @@ __device__ __forceinline__ void ns_reseed_block(const NsArgs& a, uint32_t block,
     const int waves = args_waves(a), random_boat = (a.flags & NS_RANDOM_BOAT) != 0, random_goal = (a.flags & NS_RANDOM_GOAL) != 0;
     const uint64_t env_base = static_cast<uint64_t>(a.env_offset) + base;
     constexpr uint32_t PER_WAVE = 64 / NS_RESEED_GROUP, PER_BLOCK = NS_MAIN_WAVES * PER_WAVE;
+#ifdef AQUA_NS_ONE_PASS                      // (timing experiment: no wavefront of a re-seeding block makes a second pass; results differ)
+    for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < (n_pending < PER_BLOCK ? n_pending : PER_BLOCK); qb += PER_BLOCK) {
+#else
     for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_pending; qb += PER_BLOCK) {
+#endif
         const uint32_t q = qb + (lane / NS_RESEED_GROUP);
         const bool active = q < n_pending;
         uint32_t seg = 0;
