@@ -572,6 +572,9 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     const float shaped = dsum > 0.0f ? 0.7f * (num * __builtin_amdgcn_rcpf(dsum)) : 0.0f;
 
     bool knife = (fminf(fabsf(mc), fabsf(mg)) < BAND) || (fabsf(mo) < k.band2);
+#ifdef AQUA_NO_SECOND_LOOK                   // (timing experiment: neither the second look nor the float64 path; results differ)
+    knife = false;
+#endif
     float mc_f = mc, mo_f = mo, mg_f = mg;
     if (__builtin_expect(any_lane(knife), 0)) {
         // Second look, still float32, for the worlds inside the band: the float32 margins above are limited
@@ -615,6 +618,9 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
     term = (fminf(mc_f, mo_f) < 0.0f) ? 1u : (tn > k.time_limit ? 2u : (mg_f <= 0.0f ? 3u : 0u));   // aqua.py:200-211
     reward = term == 0u ? shaped : (term == 3u ? 10.0f : -10.0f);
     e.x = xn; e.y = yn; e.th = thn; e.wx = wxn; e.wy = wyn; e.t = tn;
+#ifdef AQUA_NO_EXACT                         // (timing experiment: the second look but never the float64 path; results differ)
+    return false;
+#endif
     return knife;
 }
 
