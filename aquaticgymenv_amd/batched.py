@@ -380,6 +380,69 @@ class BatchedAqua(object):
         del keep
         return self.obs, self.reward[:n], self.term[:n]
 
+    def capture_step(self, action, noise=None, soa=False):
+        """step(action, noise=noise) captured into a HIP graph: every launch() of the returned RolloutGraph is one batched
+        step that reads `action` (and `noise`) from the caller's device buffers AS THEY ARE THEN -- the loop of
+        main/testing/__init__.py:25-34 with the policy writing its actions into a fixed buffer between replays, no
+        per-step marshalling.  action: discrete uint8/int32/int64 [N] or, continuous, float32 [2][>=N] with soa=True, on
+        this device (a buffer step() would have to convert or stage cannot be re-read by a graph: ValueError)."""
+        torch = self.torch
+        if not isinstance(action, torch.Tensor) or action.device != self.device:
+            raise ValueError("capture_step(): the action buffer must be a tensor on %s" % (self.device,))
+        if self.continuous and not soa:
+            raise ValueError("capture_step(): continuous actions as float32 [2][>=N] with soa=True")
+        counter, self.clipped_actions = self.clipped_actions, None      # (nothing steps at capture time)
+        try:
+            keep, aptr, kind, ald = self._as_action(action, soa)
+        finally:
+            self.clipped_actions = counter
+        if aptr != action.data_ptr():
+            raise ValueError("capture_step(): the action buffer must be usable as it is (dtype, contiguity)")
+        nptr, nld = None, 0
+        if noise is not None:
+            if noise.dtype != torch.float32 or noise.dim() != 2 or noise.shape[0] != 2 or noise.shape[1] < self.num_envs \
+                    or noise.stride(1) != 1 or noise.device != self.device:
+                raise ValueError("noise must be float32 [2][>=N] with unit inner stride on %s" % (self.device,))
+            nptr, nld = noise.data_ptr(), noise.stride(0)
+        lib, n = _capi.lib, self.num_envs
+        self._sync_device_tick()
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        handle = ctypes.c_void_p()
+        try:
+            with torch.cuda.device(self.device), torch.cuda.stream(cap):
+                s = self._stream()
+                _capi.check(lib.aqua_graph_begin(s), "aqua_graph_begin")
+                try:
+                    tb = self._tick_dev.data_ptr()
+                    if self.per_world:
+                        rc = lib.aqua_step_tables_f32(ctypes.byref(self.params), self._tab32.data_ptr(), self._tab64.data_ptr(),
+                                                      self.K, self.ld, self._r_max, n, self.env_offset, self.state.data_ptr(),
+                                                      self.ld, self.time.data_ptr(), aptr, kind, ald, nptr, nld, self.seed, 0,
+                                                      tb, self.reward.data_ptr(), self.term.data_ptr(),
+                                                      self.done_bits.data_ptr(), self._norm_ptr(), int(self.auto_reset), s)
+                    else:
+                        rc = lib.aqua_step_f32(ctypes.byref(self.params), self._blob_ptr(), self.K, n, self.env_offset,
+                                               self.state.data_ptr(), self.ld, self.time.data_ptr(), aptr, kind, ald, nptr, nld,
+                                               self.seed, 0, tb, self.reward.data_ptr(), self.term.data_ptr(),
+                                               self.done_bits.data_ptr(), self._norm_ptr(), int(self.auto_reset), s)
+                    if rc == 0:
+                        rc = lib.aqua_tick_advance(tb, 1, s)
+                finally:
+                    rc_end = lib.aqua_graph_end(s, ctypes.byref(handle))
+                if rc != 0 and rc_end == 0:
+                    lib.aqua_graph_destroy(handle)
+                _capi.check(rc, "capture step")
+                _capi.check(rc_end, "aqua_graph_end")
+        finally:
+            torch.cuda.current_stream(self.device).wait_stream(cap)
+        g = RolloutGraph(self, handle, 1, self.reward, self.term)
+        g._actions = (keep, noise)
+        if self.clipped_actions is not None:
+            g._clip_view = action[:, :n]
+        g.done_history = None
+        return g
+
     def _clip_view(self, steps, actions):
         """the thrusts a rollout of `steps` steps reads from `actions`, when there is a clipped-action counter to feed"""
         if self.clipped_actions is None or actions is None or isinstance(actions, str):

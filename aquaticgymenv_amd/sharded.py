@@ -64,6 +64,8 @@ def injected_faults(environ=None):
          probe       the probe block of the highest rank arrives damaged
          stall       mapping a peer's buffer never returns (the soft deadline of open_exchange() abandons it)
          rccl        the RCCL transport fails to set up
+         slow        the IPC set-up of the highest rank returns late (AQUA_TEST_SLOW_S seconds, default 6): past a shorter
+                     soft deadline its thread must stop at the next stage boundary, not finish beside the next transport
          hard-stall  the caller of open_exchange() itself stalls for kind auto / ipc (only the Watchdog ends that)"""
     raw = (os.environ if environ is None else environ).get("AQUA_TEST_EXCHANGE_FAIL", "")
     return set(w.strip() for w in raw.split(",") if w.strip())
@@ -158,6 +160,7 @@ class DoneMaskExchange(object):
         self._side_used = False           # the pump has queued work on the side streams since the last finish()
         self._faults = injected_faults()
         self.stage = getattr(self, "stage", "constructing")      # where a set-up that stalls was last seen (open_exchange())
+        self._cancel = getattr(self, "_cancel", None)            # threading.Event of open_exchange()'s sandbox, or None
         if kind == "ipc":
             self._setup_ipc()
         else:
@@ -175,6 +178,15 @@ class DoneMaskExchange(object):
         rank goes on to a collective the others never reach (a one-sided fallback would hang the job)."""
         agree(self.dist if self.collective else None, self.group, self.world, error, what)
 
+    def _enter(self, stage):
+        """Stage boundary of the set-up / probe: records where a stall would be seen, and is the CANCELLATION POINT of
+        open_exchange()'s sandbox -- once the main thread has given the attempt up (soft deadline passed, the ranks agreed
+        to move on) a set-up thread that was slow rather than stuck stops HERE, before its next collective or HIP call,
+        instead of mapping buffers and copying on streams beside the transport the run went on with."""
+        if self._cancel is not None and self._cancel.is_set():
+            raise SetupCancelled("cancelled before stage '%s' (last stage reached: '%s')" % (stage, self.stage))
+        self.stage = stage
+
     def _setup_ipc(self):
         import ctypes
         from . import _capi
@@ -182,51 +194,59 @@ class DoneMaskExchange(object):
         if "stall" in self._faults and self.rank == self.world - 1:
             self.stage = "injected fault: a set-up call that never returns"
             time.sleep(1.0e6)                  # (a daemon thread of open_exchange(): abandoned, ends with the process)
+        if "slow" in self._faults and self.rank == self.world - 1:
+            self.stage = "injected fault: a set-up call that returns late"
+            time.sleep(float(os.environ.get("AQUA_TEST_SLOW_S", "6")))
+        self._enter("starting the IPC set-up")
         if self.device.type != "cuda":
             raise RuntimeError("DoneMaskExchange(kind='ipc') moves device buffers between GPU processes: device must be a HIP device")
         lib = _capi.lib
         nbytes = self._nslots * self.world * self.steps * self.words * 8
         buf, base, raw, err = ctypes.c_void_p(), 0, b"", None
-        self.stage = "allocating and exporting the receive buffer"
-        try:                                   # (1) the own receive buffer and its handle: local, nothing collective in here
-            with torch.cuda.device(self.device):
-                _capi.check(lib.aqua_ipc_buffer_create(nbytes, ctypes.byref(buf)), "aqua_ipc_buffer_create")
-                handle = ctypes.create_string_buffer(_capi.IPC_HANDLE_BYTES)
-                _capi.check(lib.aqua_ipc_buffer_handle(buf, handle), "aqua_ipc_buffer_handle")
-                base, raw = int(lib.aqua_ipc_buffer_ptr(buf)), bytes(handle.raw)
-        except Exception as exc:
-            err = exc
-        handles = [raw]
-        self.stage = "exchanging the buffer handles"
-        if self.collective:                    # (2) every rank takes part, whatever happened to it in (1)
-            handles = [None] * self.world
-            dist.all_gather_object(handles, raw, group=self.group)
         peers = [None] * self.world
-        self.stage = "mapping the peers' receive buffers (hipIpcOpenMemHandle)"
-        if err is None:
-            try:                               # (3) map the others: local again
-                peers[self.rank] = base
-                if self.rank == self.world - 1 and "open" in self._faults:
-                    raise RuntimeError("injected fault: hipIpcOpenMemHandle failed")
-                with torch.cuda.device(self.device):
-                    for r in range(self.world):
-                        if r != self.rank:
-                            if not handles[r]:
-                                raise RuntimeError("rank %d exported no buffer" % r)
-                            p = ctypes.c_void_p()
-                            _capi.check(lib.aqua_ipc_open(handles[r], ctypes.byref(p)), "aqua_ipc_open (rank %d)" % r)
-                            peers[r] = int(p.value)
-            except Exception as exc:
-                err = exc
-        self.stage = "agreeing on the mapping"
-        try:
-            self._agree(err, "mapping the done-mask receive buffers (hipIpcMemHandle)")     # (4) all or nobody
-        except Exception:
+
+        def release():                         # what this rank holds so far (a failed agreement, a cancelled set-up)
             for r, p in enumerate(peers):
                 if r != self.rank and p:
                     lib.aqua_ipc_close(p)
             if buf.value:
                 lib.aqua_ipc_buffer_destroy(buf)
+
+        try:
+            self._enter("allocating and exporting the receive buffer")
+            try:                               # (1) the own receive buffer and its handle: local, nothing collective in here
+                with torch.cuda.device(self.device):
+                    _capi.check(lib.aqua_ipc_buffer_create(nbytes, ctypes.byref(buf)), "aqua_ipc_buffer_create")
+                    handle = ctypes.create_string_buffer(_capi.IPC_HANDLE_BYTES)
+                    _capi.check(lib.aqua_ipc_buffer_handle(buf, handle), "aqua_ipc_buffer_handle")
+                    base, raw = int(lib.aqua_ipc_buffer_ptr(buf)), bytes(handle.raw)
+            except Exception as exc:
+                err = exc
+            handles = [raw]
+            self._enter("exchanging the buffer handles")
+            if self.collective:                # (2) every rank takes part, whatever happened to it in (1)
+                handles = [None] * self.world
+                dist.all_gather_object(handles, raw, group=self.group)
+            self._enter("mapping the peers' receive buffers (hipIpcOpenMemHandle)")
+            if err is None:
+                try:                           # (3) map the others: local again
+                    peers[self.rank] = base
+                    if self.rank == self.world - 1 and "open" in self._faults:
+                        raise RuntimeError("injected fault: hipIpcOpenMemHandle failed")
+                    with torch.cuda.device(self.device):
+                        for r in range(self.world):
+                            if r != self.rank:
+                                if not handles[r]:
+                                    raise RuntimeError("rank %d exported no buffer" % r)
+                                p = ctypes.c_void_p()
+                                _capi.check(lib.aqua_ipc_open(handles[r], ctypes.byref(p)), "aqua_ipc_open (rank %d)" % r)
+                                peers[r] = int(p.value)
+                except Exception as exc:
+                    err = exc
+            self._enter("agreeing on the mapping")
+            self._agree(err, "mapping the done-mask receive buffers (hipIpcMemHandle)")     # (4) all or nobody
+        except BaseException:
+            release()
             raise
         with torch.cuda.device(self.device):
             whole = torch.as_tensor(_DevicePointerArray(base, (self._nslots, self.world, self.steps, self.words)), device=self.device)
@@ -247,21 +267,21 @@ class DoneMaskExchange(object):
         base = torch.arange(self.steps * self.words, dtype=torch.int64, device=self.device).reshape(self.steps, self.words)
         damage = 1 if ("probe" in self._faults and self.rank == self.world - 1) else 0
         err, slot, slot2 = None, 0, None
-        self.stage = "publishing the probe blocks"
+        self._enter("publishing the probe blocks")
         try:                                   # both publish paths: pump + side streams, then the in-stream fan-out launch
             slot = self.gather_async(base + (self.rank + 1) * 1000003 + damage)
             if self.kind == "ipc" and self.slots >= 2:
                 slot2 = self.gather_async(base - (self.rank + 1) * 7919, final=True)
         except Exception as exc:
             err = exc
-        self.stage = "waiting for the probe blocks"
+        self._enter("waiting for the probe blocks")
         try:                                   # (final=True leaves the producing stream to the caller: drain it, then fence)
             if self.device.type == "cuda":
                 torch.cuda.current_stream(self.device).synchronize()
             self.fence()
         except Exception as exc:
             err = err or exc
-        self.stage = "checking the probe blocks"
+        self._enter("checking the probe blocks")
         if err is None:
             try:
                 for r in range(self.world):
@@ -492,6 +512,8 @@ def agree(dist, group, world, error, what):
 # set-up threads that open_exchange() left behind in a call that had not returned (a process that has any should end with
 # os._exit once its work is done: tearing the process groups down under such a thread may not return either)
 ABANDONED_SETUP_THREADS = []
+# what set-up threads that came back late (after their attempt had been given up) had reached when they stopped
+LATE_SETUP_NOTES = []
 
 
 def open_exchange(kind, steps, words, device, slots=2, copy_engine="auto", soft_deadline_s=45.0, allow_rccl=True):
@@ -525,35 +547,60 @@ def open_exchange(kind, steps, words, device, slots=2, copy_engine="auto", soft_
         # one ends instead of sitting there when the process group is torn down)
         from datetime import timedelta
         sandbox_group = dist.new_group(backend="gloo", timeout=timedelta(seconds=soft_deadline_s + 20.0)) if collective else None
-        box = {}
+        # The main thread and the set-up thread share `box` under `lock`.  `cancel` is set by the main thread once the ranks
+        # have agreed that the attempt is off: a thread that was slow rather than stuck then stops at its next stage
+        # boundary (DoneMaskExchange._enter), releases what it holds and leaves a note; a thread that finishes the whole
+        # set-up AFTER the deadline finds `cancel` set under the lock and abandons its exchange itself -- nothing of an
+        # abandoned attempt maps buffers, copies or runs collectives beside the transport the run went on with.
+        box, lock, cancel = {}, threading.Lock(), threading.Event()
 
         def attempt():
+            ex = None
             try:
                 if torch.device(device).type == "cuda":
                     torch.cuda.set_device(torch.device(device))
-                ex = box["partial"] = DoneMaskExchange.__new__(DoneMaskExchange)
-                ex.stage = "starting"
+                ex = DoneMaskExchange.__new__(DoneMaskExchange)
+                ex.stage, ex._cancel = "starting", cancel
+                with lock:
+                    box["partial"] = ex
                 ex.__init__(steps, words, device, group=sandbox_group, kind="ipc", slots=max(2, slots), copy_engine=copy_engine)
                 ex.probe()
-                box["ex"] = ex
+                with lock:
+                    if cancel.is_set():            # finished, but too late: the run has gone on without it
+                        raise SetupCancelled("cancelled after stage '%s'" % ex.stage)
+                    box["ex"] = ex
             except BaseException as exc:
-                box["error"] = exc
+                if isinstance(exc, SetupCancelled):
+                    if ex is not None:
+                        try:
+                            ex.abandon()
+                        except Exception:
+                            pass
+                    LATE_SETUP_NOTES.append("rank %s: %s" % (os.environ.get("RANK", "0"), exc))
+                with lock:
+                    box["error"] = exc
 
         t = threading.Thread(target=attempt, name="done-mask-exchange-setup", daemon=True)
         t.start()
         t.join(soft_deadline_s)
-        if "ex" in box:
+        with lock:                                 # ONE look at the thread's outcome, after the join
+            alive = t.is_alive()
+            ex_ready, err_seen, partial = box.get("ex"), box.get("error"), box.get("partial")
+        if ex_ready is not None:
             mine = None
-        elif t.is_alive():
-            mine = TimeoutError("still in stage '%s' after %g s" % (getattr(box.get("partial"), "stage", "starting"), soft_deadline_s))
+        elif alive:
+            mine = TimeoutError("still in stage '%s' after %g s" % (getattr(partial, "stage", "starting"), soft_deadline_s))
         else:
-            mine = box.get("error") or RuntimeError("the set-up thread ended without a result")
+            mine = err_seen or RuntimeError("the set-up thread ended without a result")
         try:
             agree(dist if collective else None, None, world, mine, "the IPC done-mask exchange")
-            return box["ex"], "ipc", None
+            return ex_ready, "ipc", None
         except RuntimeError as exc:
-            if "ex" in box:
-                box["ex"].abandon()
+            with lock:
+                cancel.set()                       # from here on a late thread stops at its next stage boundary
+                late = box.get("ex")               # (it may have finished between the look above and now)
+            for built in set(e for e in (ex_ready, late) if e is not None):
+                built.abandon()
             if t.is_alive():
                 ABANDONED_SETUP_THREADS.append(t)
             if kind == "ipc":
@@ -578,6 +625,10 @@ def open_exchange(kind, steps, words, device, slots=2, copy_engine="auto", soft_
     elif kind == "rccl":
         raise RuntimeError("the RCCL transport needs a process group whose backend moves device tensors (nccl)")
     return None, None, "; ".join(notes) + ": NO done-mask exchange in this run"
+
+
+class SetupCancelled(RuntimeError):
+    """raised inside a set-up thread of open_exchange() that reaches a stage boundary after the attempt was given up"""
 
 
 class _ExchangeJob(object):

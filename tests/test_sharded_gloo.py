@@ -261,11 +261,23 @@ def _fallback_worker(rank, world, port, tmpdir, faults, soft):
             ex.fence()
             assert [int(ex.gathered[slot][r, 0, 0]) for r in range(world)] == [1, 2]
         dist.barrier()                        # the default group is untouched by whatever happened in the sandbox
+        if "slow" in faults:
+            # the set-up thread of the highest rank comes back AFTER the attempt was given up: it must stop at its next stage
+            # boundary (no buffer mapped, no collective, no copy beside the transport in use) and say how far it had come
+            from aquaticgymenv_amd import sharded
+            for th in sharded.ABANDONED_SETUP_THREADS:
+                th.join(timeout=20.0)
+            alive = any(th.is_alive() for th in sharded.ABANDONED_SETUP_THREADS)
+            outcome += "|late=%s|alive=%s" % (";".join(sharded.LATE_SETUP_NOTES), alive)
+            if ex is not None:                # ... and the transport in use still works afterwards
+                slot = ex.gather_async(torch.full((3, 4), 7 * (rank + 1), dtype=torch.int64))
+                ex.fence()
+                assert [int(ex.gathered[slot][r, 0, 0]) for r in range(world)] == [7, 14]
         with open(os.path.join(tmpdir, "out%d.txt" % rank), "w") as f:
             f.write(outcome)
     finally:
         from aquaticgymenv_amd import sharded
-        if sharded.ABANDONED_SETUP_THREADS:
+        if any(th.is_alive() for th in sharded.ABANDONED_SETUP_THREADS):
             os._exit(0)                       # (what bench.py does: a thread of this process sits in a call that never returns)
         dist.destroy_process_group()
 
@@ -286,3 +298,22 @@ def test_open_exchange_falls_back_together_on_every_rank(tmp_path, faults, soft,
         assert float(took) < soft + 15.0
         if faults == "stall":
             assert "rank 1: TimeoutError" in note                      # who stalled, where, is on the record
+
+
+def test_a_set_up_thread_that_comes_back_late_stops_at_its_next_stage(tmp_path, monkeypatch):
+    """open_exchange() used to leave a slow (not stuck) set-up thread running after the soft deadline -- it would
+    have gone on to map buffers, run collectives and copy on side streams while the run had moved to the next transport.
+    Now the main thread sets a cancel flag once the ranks have agreed to move on, and the late thread stops at its next
+    stage boundary.  Two ranks, the highest one's set-up sleeps 4 s past a 1.5-s soft deadline."""
+    monkeypatch.setenv("AQUA_TEST_SLOW_S", "4")
+    mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path), "slow", 1.5), nprocs=2, join=True)
+    for rank in range(2):
+        fields = (tmp_path / ("out%d.txt" % rank)).read_text().split("|")
+        kind, note = fields[0], fields[1]
+        assert kind == "rccl" and "rank 1: TimeoutError: still in stage 'injected fault: a set-up call that returns late'" in note
+        late, alive = fields[3], fields[4]
+        assert alive == "alive=False"
+        if rank == 1:
+            assert "cancelled before stage 'starting the IPC set-up'" in late, late
+        else:
+            assert late == "late="
