@@ -31,8 +31,11 @@ class Watchdog(object):
 
     EXIT_STATUS = 3
 
-    def __init__(self, seconds, stage, on_expire=None):
+    def __init__(self, seconds, stage, on_expire=None, status=None):
+        """status: the exit status announced and handed to on_expire (default EXIT_STATUS; bench.py's optional legs end a
+        run whose line is already safe with 0)"""
         self.stage, self.seconds = stage, float(seconds)
+        self.status = self.EXIT_STATUS if status is None else int(status)
         self._on_expire = on_expire
         self._timer = threading.Timer(self.seconds, self._expire)
         self._timer.daemon = True
@@ -40,12 +43,12 @@ class Watchdog(object):
 
     def _expire(self):
         msg = "aquaticgymenv_amd: deadline of %g s passed in stage '%s' (rank %s): exiting with status %d\n" % (
-            self.seconds, self.stage, os.environ.get("RANK", "0"), self.EXIT_STATUS)
+            self.seconds, self.stage, os.environ.get("RANK", "0"), self.status)
         try:
             sys.stderr.write(msg)
             sys.stderr.flush()
         finally:
-            (self._on_expire or os._exit)(self.EXIT_STATUS)
+            (self._on_expire or os._exit)(self.status)
 
     def cancel(self):
         self._timer.cancel()
@@ -66,6 +69,7 @@ def injected_faults(environ=None):
          rccl        the RCCL transport fails to set up
          slow        the IPC set-up of the highest rank returns late (AQUA_TEST_SLOW_S seconds, default 6): past a shorter
                      soft deadline its thread must stop at the next stage boundary, not finish beside the next transport
+         ab-stall    (bench.py) the set-up of an extra leg behind the main regions never returns on the highest rank
          hard-stall  the caller of open_exchange() itself stalls for kind auto / ipc (only the Watchdog ends that)"""
     raw = (os.environ if environ is None else environ).get("AQUA_TEST_EXCHANGE_FAIL", "")
     return set(w.strip() for w in raw.split(",") if w.strip())

@@ -47,6 +47,9 @@ GATHER_EVERY = 5     # chunks per done-mask block: one [GATHER_EVERY * CHUNK][wo
 REGIONS = 5          # timed regions at least; the median is reported
 MIN_TIMED_STEPS = 2000   # ... and at least this many timed steps in all (one default region's worth): see regions_for()
 MAX_REGIONS = 400
+ROLLBACK_BELOW_REGIONS = 20   # the untimed, rolled-back first replay of the timed graphs is made only for fewer regions than this
+AB_MIN_REGIONS = 20      # N > 1: regions of every extra leg (the other transport, the step path alone)
+OUTLIER_FACTOR = 1.5     # regions_outliers: regions slower than this x the median
 
 
 def parse(argv=None):
@@ -117,6 +120,15 @@ def parse(argv=None):
                          "clock (outside every timed interval).  A 20-step graph launched 200 us after a device "
                          "synchronisation runs 0.15-0.3 us per step faster than one launched right behind it, at the price of "
                          "3 %% of wall clock (profiles/r03/k20_settle.txt): off by default")
+    ap.add_argument("--no-exchange-ab", action="store_true",
+                    help="N > 1 (or --force-exchange): skip the extra legs behind the main regions (extras.exchange_ab: the "
+                         "step path alone, and the transport the main regions did NOT use)")
+    ap.add_argument("--ab-regions", type=int, default=None,
+                    help="regions of each extra leg; default: max(%d, the main regions' rule)" % AB_MIN_REGIONS)
+    ap.add_argument("--ab-deadline", type=float, default=120.0,
+                    help="seconds all extra legs together may take: past it rank 0 prints the line with what it has and "
+                         "extras.exchange_ab.error naming the stage, and every rank exits with status 0 (the main line is "
+                         "never lost to an optional leg)")
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel (separate line)")
     ap.add_argument("--per-world-tables", action="store_true",
                     help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
@@ -131,6 +143,10 @@ def parse(argv=None):
         args.regions_rule = "--regions"
     if args.regions < 1:
         ap.error("--regions must be >= 1")
+    if args.ab_regions is None:
+        args.ab_regions = max(AB_MIN_REGIONS, regions_for(args.steps))
+    if args.ab_regions < 1:
+        ap.error("--ab-regions must be >= 1")
     return args
 
 
@@ -342,6 +358,151 @@ def pick_median(values):
     """index of the median element (the lower one of the two middle elements for an even count)"""
     order = sorted(range(len(values)), key=lambda i: values[i])
     return order[(len(values) - 1) // 2]
+
+
+def region_outliers(us_per_step, factor=OUTLIER_FACTOR):
+    """how many regions ran slower than factor x the median, and the slowest one (the median hides a 13-us region)"""
+    if not us_per_step:
+        return {"n": 0, "factor": factor, "slowest": None}
+    med = statistics.median(us_per_step)
+    worst = max(range(len(us_per_step)), key=lambda i: us_per_step[i])
+    return {"n": sum(1 for v in us_per_step if v > factor * med), "factor": factor,
+            "slowest": {"region": worst, "us_per_step": us_per_step[worst], "x_median": us_per_step[worst] / med if med else None}}
+
+
+def summarize_regions(walls_s, events_ms, steps, n, world, a_bytes):
+    """One set of timed regions -> the figures of a line, each fraction beside the rate it follows from (SURVEY.md 8d:
+    achieved = A x steps per second): wall clock (MAX over the ranks, barrier-bracketed: `value`) and HIP events on rank
+    0's launch stream (`value_by_events`, `frac`)."""
+    wall = walls_s[pick_median(walls_s)] / steps                    # s per step
+    ev = statistics.median(events_ms) * 1e-3 / steps
+    return {"regions": len(walls_s), "wall_us_per_step": wall * 1e6, "event_us_per_step": ev * 1e6,
+            "value": world * n / wall, "value_by_events": world * n / ev,
+            "frac_by_wall": a_bytes * n / wall / 1e9 / HBM_PEAK_GBPS, "frac": a_bytes * n / ev / 1e9 / HBM_PEAK_GBPS}
+
+
+class RegionClock(object):
+    """Times sets of regions of `steps` steps on this rank.  A region: opening bracket = the closing bracket of what ran
+    before it (barrier + synchronize); the clock starts; the runner queues the steps (HIP events recorded on `stream` right
+    around its launches); drain() -- this rank's queue is empty, steps and done-mask copies; the clock stops; rendezvous().
+    Without a device (torch None: the CPU tests) the wall clock stands in for the events."""
+
+    def __init__(self, runner, steps, torch=None, dist=None, stream=None, settle_us=0.0, on_region=None):
+        self.runner, self.steps, self.torch, self.dist, self.stream = runner, steps, torch, dist, stream
+        self.settle_us, self.on_region = settle_us, on_region
+        self.regions_run = 0
+
+    def drain(self, exchange):
+        """everything this rank queued has run: the steps, and the done-mask gathers behind them on the side streams"""
+        if exchange is not None:
+            exchange.finish()
+        if self.torch is not None:
+            self.torch.cuda.synchronize()
+
+    def rendezvous(self, exchange):
+        """barrier + synchronize: the closing bracket of one region is the opening bracket of the next.  The clock of a
+        region stops at this rank's own drain() -- the region's time is the MAX over the ranks of that, which is when the
+        slowest rank was done; the barrier's own latency is not part of any region.  It is also the fence of the
+        done-mask exchange: every rank has drained, so every block published in the region is in place everywhere"""
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.torch is not None:
+                self.torch.cuda.synchronize()
+        if exchange is not None:
+            exchange.note_fence()
+
+    def run(self, n_regions, exchange):
+        """-> (wall seconds per region, event milliseconds per region, the last region's segments); call between two
+        rendezvous() (it ends with one)"""
+        walls, events, segs = [], [], []
+        torch, stream = self.torch, self.stream
+        for _ in range(n_regions):
+            if torch is not None:
+                # HIP events on the stream the step kernels are launched on, around the region's launches (the contract's
+                # `roofline` clock).  Round 2 timed a one-graph region with event-record NODES inside the graph instead:
+                # measured side by side (profiles/r03/k20_event_methods.txt) the two nodes add ~7 us of their own to a
+                # 100-us graph
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                before, after = (lambda: e0.record(stream)), (lambda: e1.record(stream))
+            else:
+                before = after = None
+            if self.settle_us > 0:
+                time.sleep(self.settle_us * 1e-6)
+            t0 = time.perf_counter()
+            segs = self.runner.run(self.steps, before_first_launch=before, after_last_launch=after, clock=True)
+            self.drain(exchange)
+            walls.append(time.perf_counter() - t0)
+            self.rendezvous(exchange)
+            events.append(e0.elapsed_time(e1) if torch is not None else walls[-1] * 1e3)          # ms
+            if self.on_region is not None:
+                self.on_region(segs)
+            self.regions_run += 1
+        return walls, events, segs
+
+
+def rolls_back_first_replay(first_replay, use_graph, by_launch, regions):
+    """whether the timed graphs the warm-up did not replay are replayed once, untimed, and taken back ahead of region 0:
+    only where region 0 could move the reported median (fewer than ROLLBACK_BELOW_REGIONS regions)"""
+    return first_replay == "rollback" and use_graph and not by_launch and regions < ROLLBACK_BELOW_REGIONS
+
+
+def exchange_ab_legs(main_kind, have_exchange):
+    """The extra legs behind the main regions of a run with a done-mask exchange (N > 1): the step path alone, then every
+    transport the main regions did NOT use -- so that ONE run on a node measures RCCL's all-gather (what BASELINE.json's
+    north_star names) even when `auto` settled on IPC peer copies, and separates what the kernels scale like from what the
+    exchange costs."""
+    if not have_exchange and main_kind is None:
+        return ["ipc", "rccl"]                      # (the main regions already are the step path alone)
+    return ["step_only"] + [k for k in ("ipc", "rccl") if k != main_kind]
+
+
+def run_exchange_ab(clock, runner, legs, open_leg, n_regions, summarize, agree, guard=None, check=None, out=None):
+    """Time `n_regions` regions per leg, one leg after the other, every rank in step.  open_leg(name) returns the leg's
+    exchange (None for "step_only") on EVERY rank or raises on every rank (sharded.open_exchange's own agreement);
+    agree(error, what) raises on every rank if any rank passes an error; summarize(walls, events) is collective (MAX of
+    the wall clocks over the ranks).  A leg that cannot be set up is recorded and skipped; a leg whose regions or check fail
+    ends the legs for every rank together -- neither touches what was measured before.  (A failure on ONE rank in the
+    middle of a region leaves the others in that region's barrier: no agreement reaches them, the guard's deadline does.)  `out` is filled as
+    the legs complete, so that a deadline (guard: a sharded.Watchdog whose stage is moved along) finds what there is."""
+    out = {} if out is None else out
+    main = runner.exchange
+    try:
+        for name in legs:
+            if guard is not None:
+                guard.stage = "exchange_ab leg '%s': set-up" % name
+            try:
+                ex = open_leg(name)
+            except Exception as exc:
+                out[name] = {"error": "set-up: %s: %s" % (type(exc).__name__, exc)}
+                continue
+            if guard is not None:
+                guard.stage = "exchange_ab leg '%s': timed regions" % name
+            runner.exchange = ex
+            err, walls, events, extra = None, None, None, None
+            try:
+                walls, events, segs = clock.run(n_regions, ex)
+                extra = check(ex, segs) if (check is not None and ex is not None) else None
+            except Exception as exc:
+                err = exc
+            try:
+                agree(err, "exchange_ab leg '%s'" % name)
+            except RuntimeError as exc:
+                out[name] = {"error": "timed regions: %s" % exc}
+                out["error"] = "legs stopped in '%s'" % name
+                if ex is not None:
+                    ex.abandon()
+                break
+            row = summarize(walls, events)
+            if extra:
+                row.update(extra)
+            out[name] = row
+            if ex is not None:
+                if guard is not None:
+                    guard.stage = "exchange_ab leg '%s': closing its exchange" % name
+                ex.close()
+    finally:
+        runner.exchange = main
+    return out
 
 
 def episodes_ended(hist, segs, np):
@@ -668,9 +829,9 @@ def main(argv=None):
     block_rows = max(chunk, min(GATHER_EVERY * CHUNK, args.steps))
     hist = [torch.zeros((block_rows, words), dtype=torch.int64, device=dev) for _ in range(2)]
     exchange, exchange_kind, exchange_note = None, None, args.exchange_note
+    slots = max([exchange_blocks(w, chunk, block_rows) for w in warmup_runs(args.warmup, args.steps)] +
+                [exchange_blocks(args.steps, chunk, block_rows), 1])
     if world > 1 or args.force_exchange:
-        slots = max([exchange_blocks(w, chunk, block_rows) for w in warmup_runs(args.warmup, args.steps)] +
-                    [exchange_blocks(args.steps, chunk, block_rows), 1])
         if watchdog is not None:
             watchdog.stage = "setting up the done-mask exchange (--exchange %s)" % args.exchange
         # no failure and no stall of a transport ends the run: ipc -> rccl -> none, decided by all ranks together
@@ -699,63 +860,59 @@ def main(argv=None):
     first_replay = ("no graph" if (by_launch or not runner.use_graph) else
                     "warm-up" if not uploaded else "hipGraphUpload (%d graph%s the warm-up does not replay)" % (uploaded, "s" * (uploaded != 1)))
 
-    def drain():
-        """everything this rank queued has run: the steps, and the done-mask gathers behind them on the side stream"""
-        if exchange is not None:
-            exchange.finish()
-        torch.cuda.synchronize()
+    node_ms, launch_ev = [], []
 
-    def rendezvous():
-        """barrier + synchronize: the closing bracket of one region is the opening bracket of the next.  The clock of a
-        region stops at this rank's own drain() -- the region's time is the MAX over the ranks of that, which is when the
-        slowest rank was done; the barrier's own latency is not part of any region.  It is also the fence of the
-        done-mask exchange: every rank has drained, so every block published in the region is in place everywhere"""
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-        if exchange is not None:
-            exchange.note_fence()
+    def diagnostics(segs):
+        launch_ev.append(runner.launch_events.elapsed_ms() if by_launch else None)
+        node_ms.append(runner.region_graph_ms(segs) if args.graph_node_events and not by_launch else None)
 
+    clock = RegionClock(runner, args.steps, torch=torch, dist=dist if distributed else None, stream=launch_stream,
+                        settle_us=args.settle_us, on_region=diagnostics)
     for i, w in enumerate(warm):
         if i:
-            rendezvous()                                 # (every run is a window of the exchange)
+            clock.rendezvous(exchange)                   # (every run is a window of the exchange)
         runner.run(w)
-        drain()
-    drain()
+        clock.drain(exchange)
+    clock.drain(exchange)
     x_before = float(env.state[0, :n].double().sum().item())
-    if args.first_replay == "rollback" and runner.use_graph and not by_launch:
+    # A timed graph the warm-up never replayed: with few regions its first launch would BE the sample (region 0 of round
+    # 3's driver line: 9.3 us per step against 5.5), so it is replayed once, untimed, and the batch put back; with
+    # ROLLBACK_BELOW_REGIONS regions or more region 0 cannot move the median and nothing runs beyond the W warm-up steps
+    # (hipGraphUpload above is a set-up call, not steps).  Either way the line says so: config.untimed_steps_beyond_warmup
+    untimed_beyond_warmup = 0
+    if rolls_back_first_replay(args.first_replay, runner.use_graph, by_launch, args.regions):
         rolled_back = runner.replay_unplayed_and_roll_back(args.steps, warm, repeats=args.ramp_replays)
         torch.cuda.synchronize()
         if rolled_back:
+            untimed_beyond_warmup = args.steps * max(1, args.ramp_replays)
             first_replay = ("one untimed replay rolled back to the state after the warm-up (%d graph%s the warm-up does not replay)"
                             % (rolled_back, "s" * (rolled_back != 1)))
-    rendezvous()
-    walls, events, launch_ev, node_ms, segs = [], [], [], [], []
-    for _ in range(args.regions):
-        # HIP events on the stream the step kernels are launched on, around the region's launches (the contract's
-        # `roofline` clock).  Round 2 timed a one-graph region with event-record NODES inside the graph instead: measured
-        # side by side (profiles/r03/k20_event_methods.txt) the two nodes add ~7 us of their own to a 100-us graph
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if args.settle_us > 0:
-            time.sleep(args.settle_us * 1e-6)
-        t0 = time.perf_counter()
-        segs = runner.run(args.steps, before_first_launch=lambda: e0.record(launch_stream),
-                          after_last_launch=lambda: e1.record(launch_stream), clock=True)
-        drain()
-        walls.append(time.perf_counter() - t0)
-        rendezvous()
-        events.append(e0.elapsed_time(e1))               # ms
-        launch_ev.append(runner.launch_events.elapsed_ms() if by_launch else None)
-        node_ms.append(runner.region_graph_ms(segs) if args.graph_node_events and not by_launch else None)
-    if distributed:
-        tmax = torch.tensor(walls, dtype=torch.float64, device="cpu" if one_gpu else dev)
+    clock.rendezvous(exchange)
+    walls, events, segs = clock.run(args.regions, exchange)
+    my_events = list(events)
+
+    def max_over_ranks(values):
+        """the region's time is when the slowest rank was done"""
+        if not distributed:
+            return list(values)
+        tmax = torch.tensor(values, dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        walls = [float(v) for v in tmax.cpu()]
+        return [float(v) for v in tmax.cpu()]
+
+    walls = max_over_ranks(walls)
+    per_rank = None
+    if distributed:
+        # every rank's own clocks: one slow GPU (or one slow link) shows here, not in a MAX
+        per_rank = [None] * ranks_seen
+        dist.all_gather_object(per_rank, {"rank": rank, "device": devices[rank] if rank < len(devices) else None,
+                                          "event_us_per_step": statistics.median(my_events) * 1e3 / args.steps,
+                                          "event_us_per_step_max": max(my_events) * 1e3 / args.steps})
+    timed_steps = args.regions * args.steps
 
     # sanity on the timed work (no cached / skipped work): every step was queued, the worlds moved, and -- with
     # restarts on -- episodes ended inside the last timed region (reported, not asserted: a one-step region right
     # after a reset may legitimately end none)
-    expect = args.warmup + args.regions * args.steps
+    expect = args.warmup + timed_steps
     if env._tick != expect or runner.steps_run != expect:
         raise RuntimeError("bench queued %d steps (env tick %d), expected %d" % (runner.steps_run, env._tick, expect))
     x_after = float(env.state[0, :n].double().sum().item())
@@ -800,8 +957,14 @@ def main(argv=None):
             "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the two clocks side by side, each rate beside the roofline fraction that follows from it (SURVEY.md 8d:
+            # achieved = A x steps per second): value <-> roofline.frac_by_wall (wall clock, MAX over the ranks, barriers
+            # between the regions); value_by_events <-> roofline.frac (HIP events on rank 0's launch stream)
+            "value_by_events": world * n / launch_s,
             "regions": args.regions, "regions_rule": args.regions_rule, "regions_ms": [w * 1e3 for w in walls],
             "region_reported": "median",
+            "regions_outliers": {"by_events": region_outliers([e * 1e3 / args.steps for e in (launch_ev if by_launch else events)]),
+                                 "by_wall": region_outliers([w * 1e6 / args.steps for w in walls])},
             "config": {"workload": "batch %d worlds/GPU, %s actions, %s, waves on, auto-reset (%s), %s of <= %d steps"
                        % (n, "continuous f32x2" if args.continuous else "discrete u8",
                           "no obstacles" if args.no_obstacles else "4 circle + 4 rect obstacles",
@@ -811,6 +974,7 @@ def main(argv=None):
                        "baseline_config": "configs[3]" if args.continuous else ("configs[1]-like" if args.no_obstacles else "configs[2]"),
                        "worlds_per_gpu": n, "global_worlds": world * n, "parallelism": "range-partition x%d" % world,
                        "launch": "eager" if by_launch else runner.launch, "timed_graph_first_replay": first_replay,
+                       "untimed_steps_beyond_warmup": untimed_beyond_warmup,
                        "done_mask_exchange": exchange is not None,
                        "done_mask_exchange_kind": exchange_kind, "done_mask_exchange_note": exchange_note,
                        "done_mask_copy_engine": args.copy_engine if exchange_kind == "ipc" else None,
@@ -819,6 +983,12 @@ def main(argv=None):
                                          if distributed else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
+                         # ... on live world-steps only (a restart tick moves no boat: sanity.restart_ticks_fraction)
+                         "frac_live": achieved / HBM_PEAK_GBPS * (1.0 - restart_frac),
+                         "frac_by_wall": a_bytes * n / (wall / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                         # the protocol-independent figure, the one to compare across rounds: the kernel's own average
+                         # duration under rocprofv3 --kernel-trace with this command's flags, committed for THIS build
+                         "kernel_only": kernel_only(n, args, a_bytes),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_world_step": a_bytes, "launch_us": launch_s * 1e6,
                          "issue_bound_us": issue_us, "issue_bound_source": issue_src,
@@ -845,23 +1015,91 @@ def main(argv=None):
                                   "graph launches.  Kernel-only duration: profiles/")},
             "sanity": {"steps_queued": runner.steps_run, "episodes_ended_last_region": ended,
                        "restart_ticks_fraction": restart_frac, "live_world_steps_per_s": steps_per_s * (1.0 - restart_frac),
+                       "live_world_steps_per_s_by_events": world * n / launch_s * (1.0 - restart_frac),
                        "done_mask_exchange_last_block": exchange_check},
         }
         if cpu is not None:
             result["cpu_baseline"], result["cpu_baseline_1core"], result["cpu_baseline_c"] = cpu
             result["host"] = host_info()
+        if per_rank is not None:
+            result["per_rank"] = per_rank
         if args.extras and world == 1:
             result["extras"] = extras(env, torch, n, a_bytes)
         if args.per_world_tables and world == 1:
             result.setdefault("extras", {})["per_world_tables"] = per_world_tables(torch, np, presets, BatchedAqua, n, dev)
-        result_out.write(json.dumps(result) + "\n")
-        result_out.flush()
+
+    # ---- the line goes out exactly once, whatever the optional legs below do
+    import threading
+    emit_lock, emitted = threading.Lock(), []
+
+    def emit():
+        with emit_lock:
+            if rank == 0 and not emitted:
+                emitted.append(True)
+                result_out.write(json.dumps(result) + "\n")
+                result_out.flush()
+
+    # ---- N > 1: the step path alone and the OTHER transport, behind the main regions (never instead of them)
+    if (exchange is not None or world > 1) and not args.no_exchange_ab:
+        a_bytes = A_CONTINUOUS if args.continuous else A_DISCRETE
+        ab = {"regions_per_leg": args.ab_regions, "main": exchange_kind or "none",
+              "what": "regions of the same K steps behind the main ones: step_only = no exchange at all; ipc / rccl = the "
+                      "transport the main regions did not use (the main one's figures are the line's own, copied here)"}
+        if rank == 0:
+            result.setdefault("extras", {})["exchange_ab"] = ab
+            ab[exchange_kind or "none"] = dict(summarize_regions(walls, events, args.steps, n, world, a_bytes),
+                                               own_block_intact=(exchange_check or {}).get("own_block_intact"),
+                                               episodes_in_peer_blocks=(exchange_check or {}).get("episodes_in_peer_blocks"))
+
+        def expired(status):
+            # an optional leg stalled: the main line is safe -- rank 0 prints it with what the legs gave, everybody leaves
+            ab["error"] = "deadline of %g s passed in stage: %s" % (args.ab_deadline, guard.stage)
+            emit()
+            os._exit(status)
+
+        guard = Watchdog(args.ab_deadline, "exchange_ab", on_expire=expired, status=0)
+
+        def open_leg(name):
+            from aquaticgymenv_amd.sharded import injected_faults
+            if "ab-stall" in injected_faults() and rank == ranks_seen - 1:
+                time.sleep(1.0e6)                       # (tests: a leg's set-up that never returns; --ab-deadline ends it)
+            if name == "step_only":
+                return None
+            if name == "rccl" and one_gpu:
+                raise RuntimeError("the ranks share one GPU and gloo carries their barriers: RCCL refuses two ranks on one device")
+            if name == "ipc" and exchange_note and "ipc unavailable" in exchange_note:
+                raise RuntimeError("not tried again: " + exchange_note)
+            ex, _, _ = open_exchange(name, block_rows, words, dev, slots=slots, copy_engine=args.copy_engine,
+                                     soft_deadline_s=min(args.soft_deadline, args.ab_deadline / 3.0), allow_rccl=not one_gpu)
+            return ex
+
+        def check_leg(ex, leg_segs):
+            got = ex.gathered[ex.last_slot()]
+            return {"own_block_intact": bool(torch.equal(got[rank], hist[leg_segs[-1][0]])),
+                    "episodes_in_peer_blocks": [int(popcount_words(got[r].cpu().numpy(), np)) for r in range(ranks_seen) if r != rank]}
+
+        def summarize_leg(leg_walls, leg_events):
+            return summarize_regions(max_over_ranks(leg_walls), leg_events, args.steps, n, world, a_bytes)
+
+        def agree_leg(error, what):
+            from aquaticgymenv_amd.sharded import agree
+            agree(dist if distributed else None, None, ranks_seen, error, what)
+
+        try:
+            run_exchange_ab(clock, runner, exchange_ab_legs(exchange_kind, exchange is not None), open_leg, args.ab_regions,
+                            summarize_leg, agree_leg, guard=guard, check=check_leg, out=ab)
+        except Exception as exc:                        # a bug in the legs' own bookkeeping must not cost the line either
+            ab["error"] = "%s: %s (stage: %s)" % (type(exc).__name__, exc, guard.stage)
+        guard.cancel()
+        if env._tick != runner.steps_run:
+            raise RuntimeError("bench queued %d steps, the batch counted %d" % (runner.steps_run, env._tick))
+    emit()
     if exchange is not None:
         exchange.close()                                 # collective: unmaps the peers' buffers behind a fence, ends the pump
     if distributed:
         dist.barrier()
         from aquaticgymenv_amd import sharded
-        if sharded.ABANDONED_SETUP_THREADS:
+        if any(th.is_alive() for th in sharded.ABANDONED_SETUP_THREADS):
             # a set-up thread of this rank is still inside a call that never returned (the soft deadline left it behind): the
             # line is out, every rank is past the barrier -- end here rather than tear the process groups down around it
             sys.stderr.flush()
@@ -902,6 +1140,30 @@ def committed_traffic(n, args):
         return None, "committed PMC pass %s is of build %s, this is %s" % (row.get("source"), row.get("library_sha16"), tag)
     return (2.0 * row["FETCH_SIZE_per_launch_raw"] * 1024.0 + row["WRITE_SIZE_per_launch_raw"] * 1024.0,
             "%s (build %s)" % (row.get("source"), tag))
+
+
+def kernel_only(n, args, a_bytes):
+    """The benchmarked kernel's own average duration under `rocprofv3 --kernel-trace --stats` (no launch gaps, no event
+    markers, no dependence on how many regions bench.py times) from the summary committed under profiles/ for THIS build
+    (the kernel-trace row of profiles/traffic.json), as a roofline fraction: the figure to compare from round to round.
+    The reason instead when there is no row for this configuration or the row is of another build."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except Exception:
+        return {"avg_ns": None, "frac": None, "source": "no profiles/traffic.json"}
+    key = "n%d_%s_%s" % (n, "cont" if args.continuous else "disc", "k0" if args.no_obstacles else "k8")
+    row = table.get(key)
+    if not row or "step_kernel_avg_ns" not in row:
+        return {"avg_ns": None, "frac": None, "source": "no committed kernel trace for " + key}
+    tag = library_tag()
+    if row.get("library_sha16") != tag:
+        return {"avg_ns": None, "frac": None,
+                "source": "committed trace %s is of build %s, this is %s" % (row.get("source"), row.get("library_sha16"), tag)}
+    ns = float(row["step_kernel_avg_ns"])
+    return {"avg_ns": ns, "calls": row.get("step_kernel_calls"), "kernel": row.get("step_kernel_name"),
+            "frac": a_bytes * n / ns / HBM_PEAK_GBPS, "source": "%s (build %s)" % (row.get("source"), tag)}
 
 
 SHADER_CLOCK_GHZ = 2.4       # measured on these kernels: profiles/r03/clock_probe.txt (2.38-2.43)

@@ -69,8 +69,23 @@ def _check_line(r, steps, warmup, n_gpus=1, envs=262144, timings_mean_something=
     frac = r["sanity"]["restart_ticks_fraction"]
     assert frac == pytest.approx(r["sanity"]["episodes_ended_last_region"] / float(steps * envs)) and 0.0 < frac < 0.1
     assert r["sanity"]["live_world_steps_per_s"] == pytest.approx(r["value"] * (1.0 - frac))
-    assert r["config"]["timed_graph_first_replay"].startswith("one untimed replay rolled back" if warmup < steps else "warm-up") or clock == "launch"
+    # a timed graph the warm-up does not replay: replayed once untimed and taken back only where region 0 could move the
+    # median (fewer than 20 regions); the line says how many steps ran beyond the W warm-up steps
+    rolled = warmup < steps and regions < 20 and clock != "launch"
+    assert r["config"]["timed_graph_first_replay"].startswith(
+        "one untimed replay rolled back" if rolled else ("hipGraphUpload" if warmup < steps else "warm-up")) or clock == "launch"
+    assert r["config"]["untimed_steps_beyond_warmup"] == (steps if rolled else 0)
     assert "issue_bound_us" in roof and "issue_bound_source" in roof
+    # one coherent line (round 5): each rate beside the fraction that follows from it, achieved = A x steps per second
+    assert roof["frac"] == pytest.approx(62 * r["value_by_events"] / n_gpus / 1e9 / 8000.0)
+    assert roof["frac_by_wall"] == pytest.approx(62 * r["value"] / n_gpus / 1e9 / 8000.0)
+    assert roof["frac_live"] == pytest.approx(roof["frac"] * (1.0 - frac))
+    assert r["sanity"]["live_world_steps_per_s_by_events"] == pytest.approx(r["value_by_events"] * (1.0 - frac))
+    for which in ("by_events", "by_wall"):
+        o = r["regions_outliers"][which]
+        assert 0 <= o["n"] < regions and o["slowest"]["x_median"] >= 1.0 and 0 <= o["slowest"]["region"] < regions
+    ko = roof["kernel_only"]
+    assert set(ko) >= {"avg_ns", "frac", "source"} and (ko["avg_ns"] is None or 0.0 < ko["frac"] < 1.0)
 
 
 @pytest.mark.gpu
@@ -144,6 +159,63 @@ def test_bench_launches_its_own_ranks():
     assert check["own_block_intact"] is True and len(check["episodes_in_peer_blocks"]) == 1
     assert check["episodes_in_peer_blocks"][0] > 0, "rank 1's done masks must have arrived at rank 0"
     assert "cpu_baseline" not in r
+
+
+@pytest.mark.gpu
+def test_two_ranks_time_the_step_path_alone_and_the_other_transport_behind_the_main_regions():
+    """round 5: ONE run with N > 1 measures more than the transport `auto` settled on -- extras.exchange_ab carries the main
+    transport's figures (the line's own), a `step_only` leg (no exchange at all: what the kernels scale like) and a leg for
+    the OTHER transport (here RCCL, which cannot exist with two ranks on one device: recorded as an error, the line
+    unharmed); per_rank shows every rank's own event clock"""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--ranks-on-one-gpu", "--envs", "65536", "--steps", "20", "--warmup", "5",
+              "--no-cpu-baseline", "--ab-regions", "25"])
+    _check_line(r, 20, 5, n_gpus=2, envs=65536, timings_mean_something=False)
+    ab = r["extras"]["exchange_ab"]
+    assert ab["main"] == "ipc" and ab["regions_per_leg"] == 25 and "error" not in ab
+    assert ab["ipc"]["regions"] == 100 and ab["ipc"]["own_block_intact"] is True
+    assert ab["ipc"]["value"] == pytest.approx(r["value"]) and ab["ipc"]["frac"] == pytest.approx(r["roofline"]["frac"])
+    so = ab["step_only"]
+    assert so["regions"] == 25 and so["value"] > 0 and so["event_us_per_step"] > 0 and "own_block_intact" not in so
+    assert "RCCL refuses two ranks on one device" in ab["rccl"]["error"] and ab["rccl"]["error"].startswith("set-up:")
+    assert [p["rank"] for p in r["per_rank"]] == [0, 1] and all(p["event_us_per_step"] > 0 and "cuda:0" in p["device"] for p in r["per_rank"])
+    assert r["sanity"]["steps_queued"] == 5 + 100 * 20          # the line's own regions; the legs ran behind them
+
+
+@pytest.mark.gpu
+def test_one_rank_under_the_launcher_measures_rccl_behind_an_ipc_main_and_the_reverse():
+    """the RCCL leg for real (one rank under torch.distributed.run, nccl process group): main regions on IPC peer copies,
+    then the step path alone, then RCCL's all-gather -- and the other way round when RCCL is asked for"""
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+            "--force-exchange", "--ab-regions", "30"]
+    r = _run(base)
+    _check_line(r, 20, 5)
+    ab = r["extras"]["exchange_ab"]
+    assert ab["main"] == "ipc" and "error" not in ab
+    for leg in ("step_only", "rccl"):
+        assert ab[leg]["regions"] == 30 and 0.05 < ab[leg]["frac"] < 1.0, (leg, ab[leg])
+    assert ab["rccl"]["own_block_intact"] is True and ab["rccl"]["episodes_in_peer_blocks"] == []
+    assert len(r["per_rank"]) == 1 and r["per_rank"][0]["event_us_per_step"] == pytest.approx(r["roofline"]["launch_us"])
+    base[base.index("--master-port") + 1] = str(_free_port())
+    r = _run(base + ["--exchange", "rccl"])
+    ab = r["extras"]["exchange_ab"]
+    assert ab["main"] == "rccl" and ab["ipc"]["own_block_intact"] is True and ab["step_only"]["regions"] == 30
+
+
+@pytest.mark.gpu
+def test_an_extra_leg_that_stalls_cannot_cost_the_line():
+    """the set-up of an extra leg never returns on the highest rank (injected): past --ab-deadline rank 0 prints the line
+    with the main regions untouched and extras.exchange_ab.error naming the stage; every rank leaves with status 0"""
+    import time
+    t0 = time.time()
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--ranks-on-one-gpu", "--envs", "65536", "--steps", "20", "--warmup", "5",
+              "--no-cpu-baseline", "--ab-deadline", "12"], faults="ab-stall")
+    assert time.time() - t0 < 240
+    _check_line(r, 20, 5, n_gpus=2, envs=65536, timings_mean_something=False)
+    ab = r["extras"]["exchange_ab"]
+    # (rank 0 itself had gone on into the leg's first region and sat in its barrier)
+    assert "deadline of 12 s passed in stage: exchange_ab leg 'step_only'" in ab["error"]
+    assert ab["ipc"]["own_block_intact"] is True and "step_only" not in ab
 
 
 @pytest.mark.gpu

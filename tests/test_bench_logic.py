@@ -382,3 +382,114 @@ def test_popcount_without_numpy2(monkeypatch):
                 raise AttributeError(name)
             return getattr(np, name)
     assert bench.popcount_words(w.view(np.int64), OldNumpy()) == 68
+
+
+# ------------------------------------------------------------------ round 5: one coherent line, and the N > 1 legs
+def test_region_outliers_name_the_slowest_region():
+    out = bench.region_outliers([5.0, 5.1, 4.9, 13.0, 5.0, 7.4])
+    assert out["n"] == 1 and out["slowest"] == {"region": 3, "us_per_step": 13.0, "x_median": 13.0 / 5.05}
+    assert bench.region_outliers([5.0] * 8)["n"] == 0 and bench.region_outliers([])["slowest"] is None
+
+
+def test_every_fraction_sits_beside_the_rate_it_follows_from():
+    """achieved = A x steps per second -- for the wall clock (value <-> frac_by_wall) and for the events
+    (value_by_events <-> frac), on one GPU and on eight (weak scaling: the fraction is per GPU)"""
+    for world in (1, 8):
+        r = bench.summarize_regions([1.2e-4, 1.0e-4, 1.1e-4], [0.11, 0.09, 0.10], 20, 262144, world, 62)
+        assert r["regions"] == 3 and abs(r["wall_us_per_step"] - 5.5) < 1e-9 and abs(r["event_us_per_step"] - 5.0) < 1e-9
+        assert abs(r["frac_by_wall"] - 62 * r["value"] / world / 1e9 / bench.HBM_PEAK_GBPS) < 1e-12
+        assert abs(r["frac"] - 62 * r["value_by_events"] / world / 1e9 / bench.HBM_PEAK_GBPS) < 1e-12
+        assert abs(r["value_by_events"] - world * 262144 / 5.0e-6) < 1.0
+
+
+def test_the_untimed_replay_is_dropped_where_region_zero_cannot_move_the_median():
+    assert bench.rolls_back_first_replay("rollback", True, False, 5)
+    assert not bench.rolls_back_first_replay("rollback", True, False, bench.regions_for(20))     # the driver's command: 100 regions
+    assert not bench.rolls_back_first_replay("upload", True, False, 5)
+    assert not bench.rolls_back_first_replay("rollback", False, False, 5) and not bench.rolls_back_first_replay("rollback", True, True, 5)
+    assert bench.parse(["--steps", "20"]).ab_regions == 100 and bench.parse([]).ab_regions == bench.AB_MIN_REGIONS
+    assert bench.parse(["--ab-regions", "3"]).ab_regions == 3
+
+
+def test_legs_of_the_exchange_ab():
+    assert bench.exchange_ab_legs("ipc", True) == ["step_only", "rccl"]          # auto settled on IPC: RCCL is measured too
+    assert bench.exchange_ab_legs("rccl", True) == ["step_only", "ipc"]
+    assert bench.exchange_ab_legs(None, False) == ["ipc", "rccl"]                # the main regions were the step path alone
+
+
+def test_region_clock_counts_and_brackets_on_the_cpu():
+    env, hist, ex = StubEnv(), _hist(20), StubExchange()
+    ex.finish = lambda: ex.log.append(("finish",))
+    ex.note_fence = lambda: ex.log.append(("fence",))
+    r = bench.StepRunner(env, None, hist, ex, use_graph=True, chunk=20)
+    r.prepare(20)
+    seen = []
+    clock = bench.RegionClock(r, 20, on_region=lambda segs: seen.append(len(segs)))
+    walls, events, segs = clock.run(3, ex)
+    assert env._tick == 60 and len(walls) == len(events) == 3 and seen == [1, 1, 1] and clock.regions_run == 3
+    assert all(abs(e - w * 1e3) < 1e-12 for e, w in zip(events, walls))           # no device: the wall clock is the event clock
+    per_region = [("wait", 0), ("gather", 0), ("finish",), ("fence",)]
+    assert ex.log == per_region * 3
+    ex.log.clear()
+    r.exchange = None
+    clock.run(2, None)
+    assert env._tick == 100 and ex.log == []
+
+
+class _Guard(object):
+    def __init__(self):
+        self.stages = []
+
+    def __setattr__(self, name, value):
+        if name == "stage":
+            self.stages.append(value)
+        object.__setattr__(self, name, value)
+
+
+def test_exchange_ab_bookkeeping_never_touches_what_was_measured():
+    env, hist = StubEnv(), _hist(20)
+    main = StubExchange()
+    r = bench.StepRunner(env, None, hist, main, use_graph=True, chunk=20)
+    r.prepare(20)
+    clock = bench.RegionClock(r, 20)
+    closed, abandoned = [], []
+
+    class Leg(StubExchange):
+        def __init__(self, name, fail_in_run=False):
+            StubExchange.__init__(self)
+            self.name, self.fail_in_run = name, fail_in_run
+
+        def finish(self):
+            if self.fail_in_run:
+                raise OSError("link down")
+
+        def note_fence(self):
+            pass
+
+        def close(self):
+            closed.append(self.name)
+
+        def abandon(self):
+            abandoned.append(self.name)
+
+    def open_leg(name):
+        if name == "ipc":
+            raise RuntimeError("cannot map")
+        return None if name == "step_only" else Leg(name, fail_in_run=(name == "broken"))
+
+    def agree(error, what):
+        if error is not None:
+            raise RuntimeError("%s failed on 1 of 1 ranks (%s)" % (what, error))
+
+    guard, out = _Guard(), {"main": "x"}
+    got = bench.run_exchange_ab(clock, r, ["step_only", "ipc", "rccl", "broken", "never"], open_leg, 2,
+                                lambda w, e: {"n": len(w)}, agree, guard=guard, check=lambda ex, segs: {"checked": ex.name}, out=out)
+    assert got is out and out["main"] == "x"
+    assert out["step_only"] == {"n": 2}                                           # no exchange: nothing to check or close
+    assert out["ipc"] == {"error": "set-up: RuntimeError: cannot map"}            # recorded, skipped, the legs go on
+    assert out["rccl"] == {"n": 2, "checked": "rccl"} and closed == ["rccl"]
+    assert "link down" in out["broken"]["error"] and out["error"] == "legs stopped in 'broken'" and abandoned == ["broken"]
+    assert "never" not in out                                                      # a leg that failed while running ends the legs
+    assert r.exchange is main                                                      # ... and the runner is back on the main transport
+    assert env._tick == r.steps_run == 2 * 20 * 2 + 20                             # two legs ran 2 regions; the broken one's first region
+    assert guard.stages[0] == "exchange_ab leg 'step_only': set-up" and "exchange_ab leg 'rccl': closing its exchange" in guard.stages

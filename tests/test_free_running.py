@@ -65,8 +65,9 @@ def _run(torch, cfg, z, ti, n, mode):
     from aquaticgymenv_amd.batched import BatchedAqua
     env = BatchedAqua(n, obstacles=cfg["obstacles"], waves=bool(cfg["waves"]), continuous=cfg["continuous"], seed=99,
                       auto_reset=False, device="cuda:0")
+    # (the reference's start state is float64 out of its own reset(): rounding it to float32 is the first, and largest
+    # single, step of the drift -- up to half an ulp of a coordinate, 3.8e-6)
     s0 = z["traj%d_state0" % ti].astype(np.float32)
-    assert np.array_equal(s0.astype(np.float64), z["traj%d_state0" % ti]), "start states are float32-representable"
     env.set_state(np.repeat(s0[None], n, axis=0), np.zeros(n, dtype=np.int32))
     noise_all = torch.as_tensor(z["traj%d_noise_u" % ti].astype(np.float32)).cuda()          # [T][2]
     if cfg["continuous"]:

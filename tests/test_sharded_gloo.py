@@ -317,3 +317,93 @@ def test_a_set_up_thread_that_comes_back_late_stops_at_its_next_stage(tmp_path, 
             assert "cancelled before stage 'starting the IPC set-up'" in late, late
         else:
             assert late == "late="
+
+
+# ------------------------------------------------------------------ round 5: the extra legs behind the main regions
+def _ab_worker(rank, world, port, tmpdir, fail_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        import bench
+        from aquaticgymenv_amd.sharded import agree
+        steps, words = 20, 8
+        hist = [torch.zeros((steps, words), dtype=torch.int64) for _ in range(2)]
+        main, kind, _ = open_exchange("rccl", steps, words, "cpu", slots=2)          # (gloo stands in for RCCL on CPU tensors)
+        env = _MaskEnv(rank)
+        runner = bench.StepRunner(env, None, hist, main, use_graph=False, chunk=steps)
+        clock = bench.RegionClock(runner, steps, dist=dist)
+        clock.rendezvous(main)
+        walls, events, segs = clock.run(3, main)                                      # the "main regions"
+
+        def max_over_ranks(values):
+            t = torch.tensor(values, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(v) for v in t]
+
+        class Flaky(object):
+            """the second RCCL leg's exchange: what arrived turns out damaged on ONE rank (found by the leg's check, when
+            every rank is out of its regions -- a failure INSIDE a region leaves the other ranks in that region's barrier,
+            which only a deadline ends: tests/test_00_bench_child.py, --ab-deadline)"""
+            def __init__(self, ex):
+                self.ex = ex
+
+            def __getattr__(self, name):
+                return getattr(self.ex, name)
+
+            def last_slot(self):
+                if rank == fail_rank:
+                    raise OSError("injected: the last block arrived damaged")
+                return self.ex.last_slot()
+
+        def open_leg(name):
+            if name == "step_only":
+                return None
+            ex, _, _ = open_exchange(name.split("#")[0], steps, words, "cpu", slots=2, soft_deadline_s=10.0)
+            return Flaky(ex) if name.endswith("#flaky") else ex
+
+        def check(ex, leg_segs):
+            got = ex.gathered[ex.last_slot()]
+            return {"own_block_intact": bool(torch.equal(got[rank], hist[leg_segs[-1][0]])),
+                    "peer_first_words": [int(got[r][0, 0]) for r in range(world) if r != rank]}
+
+        out = {}
+        bench.run_exchange_ab(clock, runner, ["step_only", "ipc", "rccl", "rccl#flaky", "rccl"], open_leg, 4,
+                              lambda w, e: bench.summarize_regions(max_over_ranks(w), e, steps, 512, world, 62),
+                              lambda err, what: agree(dist, None, world, err, what), check=check, out=out)
+        assert runner.exchange is main
+        dist.barrier()                                        # both ranks are still in step with each other ...
+        tick0 = env._tick
+        clock.run(1, main)                                    # ... and the main transport still works
+        block = main.gathered[main.last_slot()]
+        assert [int(block[r, 0, 0]) for r in range(world)] == [r * 1000 + tick0 + 1 for r in range(world)]
+        with open(os.path.join(tmpdir, "ab%d.json" % rank), "w") as f:
+            json.dump({"out": out, "tick": env._tick, "steps_run": runner.steps_run}, f)
+        main.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_extra_legs_run_in_step_on_two_ranks_and_a_failing_leg_ends_them_together(tmp_path):
+    """bench.py's exchange_ab over gloo, two ranks: the step path alone; a transport that cannot be set up (IPC without a
+    HIP device: an error on every rank, skipped); the collective transport with its own block check; a leg that FAILS on
+    rank 1 inside a timed region -- both ranks stop the legs together (nobody sits in a collective the other left), what
+    was measured stays, and the main transport goes on working"""
+    import json
+    mp.spawn(_ab_worker, args=(2, _free_port(), str(tmp_path), 1), nprocs=2, join=True)
+    for rank in range(2):
+        rec = json.loads((tmp_path / ("ab%d.json" % rank)).read_text())
+        out = rec["out"]
+        assert out["step_only"]["regions"] == 4 and "own_block_intact" not in out["step_only"]
+        assert out["ipc"]["error"].startswith("set-up:") and "ipc" in out["ipc"]["error"]
+        assert out["rccl"]["regions"] == 4 and out["rccl"]["own_block_intact"] is True
+        assert out["rccl"]["peer_first_words"][0] % 1000 > 0                       # the peer's rows arrived
+        assert "timed regions" in out["rccl#flaky"]["error"] and "rank 1: OSError: injected" in out["rccl#flaky"]["error"]
+        assert out["error"] == "legs stopped in 'rccl#flaky'"
+        # 3 main regions + 4 (step_only) + 4 (rccl) + the flaky leg's regions up to its failure + 1 closing region
+        assert rec["tick"] == rec["steps_run"] and rec["tick"] >= 20 * (3 + 4 + 4 + 1 + 1)
+    a = json.loads((tmp_path / "ab0.json").read_text())["out"]
+    b = json.loads((tmp_path / "ab1.json").read_text())["out"]
+    assert a["rccl"]["value"] == b["rccl"]["value"]                                # the MAX over the ranks is everybody's
