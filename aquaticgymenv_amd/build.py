@@ -61,6 +61,37 @@ def build_variant(name, flags, verbose=False):
     return out
 
 
+class NoSanitizerRuntime(RuntimeError):
+    pass
+
+
+def build_hostsan(verbose=False):
+    """lib/variants/libaqua_hip_hostsan.so: the HOST half of the library (argument validation, the blob / table packers,
+    graph / event / IPC handle bookkeeping) instrumented with AddressSanitizer + UBSan; device code untouched
+    (-fno-gpu-sanitize: no instrumented kernels, no xnack code objects -- GPU ASan does not exist on this pool and is never
+    asked for).  CPU box only: tests/test_sanitizers.py runs tests/test_capi_cpu.py against it in a child process with the
+    runtime preloaded.  -> (library path, path of clang's shared ASan runtime to preload)."""
+    cc = hipcc_path()
+    clang = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(cc))), "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = shutil.which("amdclang") or shutil.which("clang") or ""
+    runtime = ""
+    if clang:
+        runtime = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+        if not os.path.isabs(runtime):           # newer layouts: lib/<triple>/libclang_rt.asan.so
+            runtime = subprocess.run([clang, "-print-file-name=libclang_rt.asan.so"], capture_output=True, text=True).stdout.strip()
+    if not runtime or not os.path.isabs(runtime) or not os.path.exists(runtime):
+        raise NoSanitizerRuntime("hipcc's clang has no shared AddressSanitizer runtime (looked for libclang_rt.asan-x86_64.so)")
+    out = os.path.join(HERE, "lib", "variants", "libaqua_hip_hostsan.so")
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS + [os.path.abspath(__file__)]):
+        return out, runtime
+    # -DAQUA_DEV_U8_ONLY: the device side is compiled for one action kind instead of seven (a sixth of the compile time);
+    # the host code under test -- validation, packers, handles -- is the same, only the launch tables are shorter
+    flags = ["-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+             "-fno-gpu-sanitize", "-shared-libsan", "-DAQUA_DEV_U8_ONLY"]
+    return build_variant("hostsan", flags, verbose=verbose), runtime
+
+
 if __name__ == "__main__":
     if "--variants" in sys.argv:
         for name, flags in (("stamps", ["-DAQUA_STAMPS=1"]), ("nw", ["-DAQUA_NS_NOWORK"]), ("nm", ["-DAQUA_NS_NOMAIN"])):

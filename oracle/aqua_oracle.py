@@ -24,11 +24,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libaqua_oracle.so")
+# AQUA_ORACLE_LIB: another build of the same source (oracle/Makefile `asan`), used as it is -- tests/test_sanitizers.py
+_LIB_OVERRIDE = os.environ.get("AQUA_ORACLE_LIB")
 
 ACTION_U8, ACTION_I32, ACTION_I64, ACTION_F32X2 = 0, 1, 2, 3
 
 
 def build(force=False):
+    if _LIB_OVERRIDE:
+        return _LIB_OVERRIDE
     src = os.path.join(_HERE, "aqua_oracle.c")
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libaqua_oracle.so"])

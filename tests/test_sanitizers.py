@@ -1,0 +1,89 @@
+"""SURVEY.md section 5, sanitizer row -- on the CPU box only (GPU AddressSanitizer / xnack runs do not exist on this pool).
+
+(a) the C oracle (oracle/aqua_oracle.c, the checker of every parity test) built with -fsanitize=address,undefined
+    (oracle/Makefile `asan`) and driven through tests/test_oracle_golden.py -- golden vectors, the reference's
+    trajectories, every entry point at ragged sizes with exactly-sized buffers -- in a child process with the ASan runtime
+    preloaded;
+(b) the HOST half of the product library (argument validation, the obstacle-blob and per-world-table packers, handle
+    bookkeeping: the extern "C" block of csrc/aqua_hip.hip) built with host-side ASan + UBSan, device code untouched
+    (aquaticgymenv_amd/build.py build_hostsan), and driven through tests/test_capi_cpu.py by way of AQUA_HIP_LIB, again
+    in a child with the runtime preloaded.
+Both skip cleanly when the toolchain has no sanitizer runtime.  Neither ever runs on the GPU box (-m "not gpu" only)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# leaks: CPython and torch hold memory until exit by design; ODR / alloc-dealloc: torch's own libraries, not the code under test
+ASAN_OPTIONS = "detect_leaks=0:abort_on_error=0:halt_on_error=1:detect_odr_violation=0:alloc_dealloc_mismatch=0:exitcode=97"
+UBSAN_OPTIONS = "print_stacktrace=1:halt_on_error=1:exitcode=98"
+
+
+def _child(cmd, preload, extra_env, timeout=1500, expect_report=None):
+    env = dict(os.environ)
+    env.update(extra_env)
+    # PYTHONMALLOC=malloc: ctypes and numpy buffers come straight from malloc, so the runtime sees their bounds
+    env.update({"LD_PRELOAD": preload, "ASAN_OPTIONS": ASAN_OPTIONS, "UBSAN_OPTIONS": UBSAN_OPTIONS, "OMP_NUM_THREADS": "4",
+                "PYTHONMALLOC": "malloc"})
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if expect_report:
+        assert "ERROR: AddressSanitizer" in p.stderr and expect_report in p.stderr and p.returncode != 0, \
+            "the instrumented build did not report a deliberate overflow:\n" + p.stderr[-3000:]
+        return p
+    text = p.stdout[-4000:] + "\n--- stderr\n" + p.stderr[-6000:]
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, text
+    assert p.returncode == 0, "rc %d\n%s" % (p.returncode, text)
+    return p
+
+
+def _mapped(lib_name, preload, extra_env):
+    """the child process really has `lib_name` and the sanitizer runtime mapped (not the plain build)"""
+    code = ("import sys; sys.path.insert(0, %r)\n%s\n"
+            "maps = open('/proc/self/maps').read()\nprint('MAPPED', %r in maps, 'asan' in maps)" %
+            (ROOT, extra_env.pop("_import"), lib_name))
+    p = _child([sys.executable, "-c", code], preload, extra_env, timeout=600)
+    assert "MAPPED True True" in p.stdout, p.stdout + p.stderr[-2000:]
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers():
+    gcc = shutil.which(os.environ.get("CC", "gcc"))
+    if gcc is None:
+        pytest.skip("no C compiler")
+    runtime = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not runtime or not os.path.isabs(runtime) or not os.path.exists(runtime):
+        pytest.skip("this gcc has no libasan")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    lib = os.path.join(ROOT, "oracle", "libaqua_oracle_asan.so")
+    _mapped("libaqua_oracle_asan.so", runtime, {"AQUA_ORACLE_LIB": lib,
+                                                 "_import": "from oracle.aqua_oracle import COracle; COracle().threads()"})
+    p = _child([sys.executable, "-m", "pytest", os.path.join("tests", "test_oracle_golden.py"), "-x", "-q", "-p", "no:cacheprovider"],
+               runtime, {"AQUA_ORACLE_LIB": lib})
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-2000:]
+    # control: the instrumentation is live -- a reward array one world short is reported as a heap overflow in the oracle
+    code = ("import sys; sys.path.insert(0, %r)\nimport ctypes, numpy as np\nfrom oracle.aqua_oracle import COracle, _p\n"
+            "o = COracle(); n = 300\ns = np.zeros((7, n)); s[0:2] = 50; t = np.zeros(n, dtype=np.int32)\n"
+            "a = np.zeros(n, dtype=np.uint8); r = np.empty(n - 1); c = np.empty(n, dtype=np.uint8)\n"
+            "o.lib.aqua_oracle_step(n, 0, None, 1, _p(s, ctypes.c_double), _p(t, ctypes.c_int32), 0, a.ctypes.data_as(ctypes.c_void_p),"
+            " None, 1, 0, 0, _p(r, ctypes.c_double), _p(c, ctypes.c_uint8), None)\n" % ROOT)
+    _child([sys.executable, "-c", code], runtime, {"AQUA_ORACLE_LIB": lib}, expect_report="heap-buffer-overflow")
+
+
+def test_host_half_of_the_product_library_under_sanitizers():
+    from aquaticgymenv_amd import build
+    try:
+        lib, runtime = build.build_hostsan()
+    except build.NoSanitizerRuntime as exc:
+        pytest.skip(str(exc))
+    _mapped(os.path.basename(lib), runtime, {"AQUA_HIP_LIB": lib, "_import": "from aquaticgymenv_amd import _capi"})
+    p = _child([sys.executable, "-m", "pytest", os.path.join("tests", "test_capi_cpu.py"), "-x", "-q", "-p", "no:cacheprovider"],
+               runtime, {"AQUA_HIP_LIB": lib})
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-2000:]
+    # control: a per-world table buffer one row short is reported as a heap overflow inside aqua_pack_tables
+    code = ("import sys; sys.path.insert(0, %r)\nimport ctypes, numpy as np\nfrom aquaticgymenv_amd import _capi\n"
+            "n, k, ld = 100, 4, 128\nrows = np.zeros((n, k, 5)); rows[:, :, 3] = 1.0\n"
+            "t32 = np.zeros((k - 1, 6, ld), dtype=np.float32); t64 = np.zeros((k, 5, ld)); r = ctypes.c_float(0)\n"
+            "_capi.lib.aqua_pack_tables(rows.ctypes.data, k, n, ld, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r))\n" % ROOT)
+    _child([sys.executable, "-c", code], runtime, {"AQUA_HIP_LIB": lib}, expect_report="heap-buffer-overflow")
