@@ -6,6 +6,7 @@ without libaqua_hip.so raises.
 
 Reference being replaced: one Python object per world, gym_aqua/envs/aqua.py:9-213.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -13,6 +14,7 @@ import numpy as np
 from . import _capi, presets
 
 TIME_LIMIT = 1000          # aqua.py:91
+_NO_CONTEXT = contextlib.nullcontext()
 
 
 def _round_up(n, m):
@@ -93,12 +95,22 @@ class RolloutGraph(object):
     def launch(self, stream=None):
         """Replay the graph.  stream: the HIP stream as a ctypes.c_void_p marshalled once by a caller that replays in a tight
         loop (bench.py: ~3 us of host time per replay sit between an event recorded ahead of the launch and the launch
-        itself, and on an idle stream they count: profiles/r04/launch_gap/); default: torch's current stream."""
+        itself, and on an idle stream they count: profiles/r04/launch_gap/); default: torch's current stream.  A stream other
+        than torch's current one is fine: what launch() itself queues ahead of the replay (the tick-base refresh after a
+        step()/reset()/restore() in between, the clipped-action count) is queued on THAT stream; the buffers the graph reads
+        (actions, injected noise) are the caller's to order."""
         env = self._env
-        if env._device_tick != env._tick:
-            env._sync_device_tick()
-        if self._clip_view is not None:
-            env._count_clipped(self._clip_view)        # (count_clipped=True: a replay steps with the buffer's CURRENT content)
+        if env._device_tick != env._tick or self._clip_view is not None:
+            # the tick-base refresh and the clipped-action count are small torch operations: they must be ordered ahead of the
+            # replay, so they go to the stream the replay goes to (torch's current one unless the caller named another)
+            torch = env.torch
+            other = stream is not None and stream.value != torch.cuda.current_stream(env.device).cuda_stream
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream.value, device=env.device)) if other else _NO_CONTEXT
+            with ctx:
+                if env._device_tick != env._tick:
+                    env._sync_device_tick()
+                if self._clip_view is not None:
+                    env._count_clipped(self._clip_view)        # (count_clipped=True: a replay steps with the buffer's CURRENT content)
         rc = self._launch(self._handle, stream if stream is not None else env._stream())
         if rc:
             _capi.check(rc, "aqua_graph_launch")

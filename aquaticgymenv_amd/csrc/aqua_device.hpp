@@ -504,11 +504,16 @@ enum : int { QUICK_NEVER = 0, QUICK_ALWAYS = 1, QUICK_IF_PRESENT = 2 };
 // KREG > 0 (PER_WORLD only): the caller has read the lane's first KREG rows into registers (`regs`, loaded with the
 // state, one memory round trip for everything; rows past the table's end repeat its last row, which leaves a minimum
 // unchanged) and the first look is arithmetic only; the second look and the float64 path (rare) still read `wt`.
-template <bool PER_WORLD = false, int QUICK = QUICK_NEVER, int KREG = 0>
+// SINK (PER_WORLD with KREG == 0 only): a lane whose `sink` is not NULL leaves every row it reads, as it reads it, at
+// sink[5 j .. 5 j + 4] (cx, cy, hx, hy, r2; an LDS slot of the caller's) -- the rows of a world that restarts this tick,
+// for the lanes that re-seed it (reset_env_group<.., RESEED_LDS5>): they ride along with the wavefront's own coalesced row
+// loads instead of being fetched again, one 128-byte line per float, by the re-seeding group.
+template <bool PER_WORLD = false, int QUICK = QUICK_NEVER, int KREG = 0, bool SINK = false>
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
                                           const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr,
-                                          const ObstF* regs = nullptr)
+                                          const ObstF* regs = nullptr, float* sink = nullptr)
 {
+    static_assert(!SINK || (PER_WORLD && KREG == 0), "rows are left behind by the loop that streams them");
     float s, c;
     sincos_bounded(e.th + h, s, c);
     const float ddx = fmaf(-chord, s, e.wx);               // displacement incl. wave drift (old wave, aqua.py:180-181)
@@ -533,6 +538,12 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
 #pragma unroll 2
         for (int j = 0; j < k.K; ++j) {                    // a circle is a box with zero half extents: same bits
             const ObstF r = world_row(*wt, j);
+            if constexpr (SINK) {
+                if (sink != nullptr) {
+                    float* const d = sink + 5 * j;
+                    d[0] = r.cx; d[1] = r.cy; d[2] = r.hx; d[3] = r.hy; d[4] = r.r2;
+                }
+            }
             const float dx = fmaxf(fabsf(xn - r.cx) - r.hx, 0.0f);
             const float dy = fmaxf(fabsf(yn - r.cy) - r.hy, 0.0f);
             mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -r.r2)));
@@ -801,7 +812,10 @@ __device__ __forceinline__ EnvState reset_env_world(uint64_t seed, uint64_t env,
 // of G lanes side by side; every group makes the same G attempts, each against its own SOA_ROWS / SOA_SPLIT rows, and the
 // hits are OR-ed across the groups before anything is decided (a pass over a long table is then SOA_SPLIT times
 // shorter; everything downstream is computed redundantly, and identically, by every group).
-constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5, RESEED_HANDOFF16 = -6;
+// ROWS == RESEED_LDS5: per-world tables of ANY length whose rows the world's own lane left in LDS while it streamed them
+// (fast_step<.., SINK>): `rows` points at the slot, K rows of five floats (cx, cy, hx, hy, r2) back to back; two rows in
+// registers at a time, a run-time loop.  The rare serial scan reads the table in memory (`wt`).
+constexpr int RESEED_QUICK = -1, RESEED_WORLD = -2, RESEED_HANDOFF8 = -4, RESEED_SOA = -5, RESEED_HANDOFF16 = -6, RESEED_LDS5 = -7;
 template <int G, int ROWS = 0, int SOA_ROWS = 8, int SOA_STRIDE = 256, int SOA_SPLIT = 1>
 __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, uint64_t env, uint64_t tick, int waves,
                                                      int random_boat, int random_goal, int K, ObstPtr t,
@@ -900,6 +914,16 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 hit_g = ((mg >> sub) & every) != 0ull;
                 hit_b = ((mb >> sub) & every) != 0ull;
             }
+        } else if constexpr (ROWS == RESEED_LDS5) {
+            const float* const slot = reinterpret_cast<const float*>(rows);
+#pragma unroll 1
+            for (int j = 0; j < K; j += 2) {             // two rows in registers; an odd K tests its last row twice
+                const float* const r0 = slot + 5 * j;
+                const float* const r1 = slot + 5 * (j + 1 < K ? j + 1 : j);
+                const float c0[5] = {r0[0], r0[1], r0[2], r0[3], r0[4]}, c1[5] = {r1[0], r1[1], r1[2], r1[3], r1[4]};
+                test(c0[0], c0[1], c0[2], c0[3], c0[4]);
+                test(c1[0], c1[1], c1[2], c1[3], c1[4]);
+            }
         } else if constexpr (ROWS == RESEED_WORLD) {
 #pragma unroll 1
             for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
@@ -961,7 +985,8 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 const float fx = gx - cx, fy = gy - cy;
                 const float fy2 = fy * fy;
                 if (fmaf(fx, fx, fy2) <= 25.0f) continue;
-                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_HANDOFF16 || ROWS == RESEED_SOA) {
+                if constexpr (ROWS == RESEED_WORLD || ROWS == RESEED_HANDOFF8 || ROWS == RESEED_HANDOFF16 || ROWS == RESEED_SOA ||
+                              ROWS == RESEED_LDS5) {
                     WorldRows uncached;
                     uncached.cached = false;
                     if (reset_hit_world(K, *wt, uncached, cx, cy)) continue;

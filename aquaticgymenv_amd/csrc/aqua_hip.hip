@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
+#include <type_traits>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -292,7 +293,7 @@ __device__ unsigned long long* g_stamps = nullptr;
             g_stamps[(static_cast<size_t>(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64) * 8 + (slot)] = t_; \
     } while (0)
 // AQUA_STAMPS == 2: only the wavefront-start (3) and wavefront-end (2) wall-clock stamps, to perturb less
-// AQUA_STAMPS == 3: those two, kept per launch for the last 32 launches (tools/r03/burst_timeline.py)
+// AQUA_STAMPS == 3: those two, kept per launch for the last 32 launches (profiles/r03/scripts/burst_timeline.py)
 #if AQUA_STAMPS == 3
 template <typename A> __device__ __forceinline__ uint64_t launch_tick(const A& a);
 #define AQUA_STAMP(slot) do { } while (0)
@@ -422,9 +423,12 @@ __device__ __forceinline__ T kernarg_at(size_t off)
     return *(const T __attribute__((address_space(4)))*)(kp + off);
 }
 
-template <typename A = StepArgs>
-__device__ __forceinline__ void tick_housekeeping()
+// (A is deduced from the kernel's own parameter, never defaulted: a kernel that took NsArgs and read StepArgs' offsets
+// would dereference a pointer from the wrong word of its argument segment)
+template <typename A>
+__device__ __forceinline__ void tick_housekeeping(const A&)
 {
+    static_assert(std::is_standard_layout<A>::value, "offsetof() into the kernel-argument segment needs a standard-layout struct");
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t* const copy_to = kernarg_at<uint64_t*>(offsetof(A, tick_copy_to));
         uint64_t* const bump_to = kernarg_at<uint64_t*>(offsetof(A, tick_bump_to));
@@ -488,6 +492,9 @@ __device__ __forceinline__ int32_t done_code(uint64_t tick) { return -1 - static
 __device__ __forceinline__ int32_t restart_code(uint64_t tick) { return -3 - static_cast<int32_t>(tick & 1u); }
 
 constexpr int NS_TABLE_ROWS = 8;   // tables of up to this many obstacles are staged in LDS for the re-seeding pass (0: never)
+// launch_step() / launch_step_ns_range() pick the SMALL_TABLE kernels by K <= NS_TABLE_ROWS, and those read the quick table
+// (QUICK_ALWAYS, RESEED_QUICK), which aqua_pack_obstacles() writes only for K <= QUICK_MAX
+static_assert(NS_TABLE_ROWS <= QUICK_MAX, "the SMALL_TABLE kernels read a quick table that exists only for K <= QUICK_MAX");
 struct NsReseedShared {
     ObstF rows[NS_TABLE_ROWS > 0 ? NS_TABLE_ROWS : 1];
     uint32_t count[NS_MAIN_WAVES];
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
 {
     __shared__ NsReseedShared sh;
     AQUA_RTSTAMP(3);        // wavefront started
-    tick_housekeeping<NsArgs>();
+    tick_housekeeping(a);
     bool reseed_role;
     uint32_t role_index;
     if (!ns_role<INTERLEAVE>(a.reseed_blocks, (a.N + NS_TILE - 1) / NS_TILE, reseed_role, role_index)) return;
@@ -857,6 +864,133 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
     }
 }
 
+// The next-step fused rollout's hand-over (round 5): NO barrier, a wavefront of its own that only re-seeds, and TWO steps of
+// slack for it.  A world that finishes at step s is not needed again before step s + 2 (during step s + 1 it does not
+// move: that tick reports reward 0 / term 0), and what it restarts with is a function of (seed, world, tick s + 1) alone.
+// So its lane posts it the moment `done` is known, at the END of step s, and collects the fresh state right before it
+// moves again, in step s + 2; in between a fifth wavefront of the block -- it owns no worlds -- runs the re-seeding pass
+// (~0.9 us of dependent arithmetic) beside two whole steps of the other four.  The wavefronts meet only through sequence
+// numbers in LDS.  Post p of a tile (p = 0: the worlds that came into the launch marked done; p = s + 1: the worlds that
+// finished at step s), global sequence q = q0 + p:
+//   post     every stepping wavefront lists its lanes that need a fresh state (list / count, double-buffered by the parity
+//            of q) and sets posted[wave] = q + 1; before it overwrites the lists of q - 2 it makes sure q - 2 was served.
+//   serve    the re-seeding wavefront waits for posted[*] > q, re-seeds the listed worlds with the draws of tick0 + p (eight
+//            lanes per world) into result[parity][wave * 64 + position] and sets served = q + 1.
+//   collect  a wavefront with lanes on list q waits for served > q right before those lanes move again.
+// History: with two block-wide barriers per step and the pass on a rotating duty wavefront (the same-step mode's protocol
+// below, and this mode's until round 4) three wavefronts of four idle through every pass: 4.05 us per step where the steps
+// alone take 1.40.  A fifth wavefront with the post at the top of step s + 1 (one step of slack) measured 3.60-3.78
+// (profiles/r04/fused_mail/).  Every wait is bounded: one that sees no progress for MAIL_SPIN_LIMIT polls gives up (the
+// results are then wrong, every test compares them, and the grid drains).
+#ifndef AQUA_FUSED_MAIL
+#define AQUA_FUSED_MAIL 1                                   // (0: the barrier protocol for the next-step mode too -- A/B timing)
+#endif
+#ifndef AQUA_MAIL_SPIN_LIMIT
+#define AQUA_MAIL_SPIN_LIMIT (1u << 18)                    // polls of ~0.1 us; a wait that is answered takes a few
+#endif
+constexpr uint32_t MAIL_SPIN_LIMIT = AQUA_MAIL_SPIN_LIMIT;
+#ifndef AQUA_MAIL_PRIO
+#define AQUA_MAIL_PRIO 0
+#endif
+struct RolloutMail {
+    uint32_t posted[BLOCK_SMALL / 64];
+    uint32_t served;
+    uint32_t count[2][BLOCK_SMALL / 64];
+    uint8_t list[2][BLOCK_SMALL / 64][64];
+    float result[2][BLOCK_SMALL][8];
+};
+
+// The flags and what they guard all live in LDS, which serves one wavefront's instructions in the order they were issued:
+// data first, flag second on the writing side; flag first, data second on the reading side.  Plain accesses with compiler
+// barriers are therefore enough -- and they must be all there is: an acquire / release at workgroup scope compiles to
+// s_waitcnt vmcnt(0), which parks the wavefront behind its own reward / term stores to HBM at every step (measured in round
+// 4: the protocol alone 1.1 us per step instead of 0.3).  ds instructions by hand: a volatile access through a generic
+// pointer becomes a FLAT load, with vmcnt(0) as well.
+__device__ __forceinline__ uint32_t lds_offset(const void* p)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
+}
+__device__ __forceinline__ void mail_wait(const uint32_t* flag, uint32_t at_least)
+{
+    const uint32_t at = lds_offset(flag);
+    for (uint32_t polls = 0; polls < MAIL_SPIN_LIMIT; ++polls) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at) : "memory");
+        if (uni(v) >= at_least) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void mail_flag(uint32_t* flag, uint32_t value)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(lds_offset(flag)), "v"(value) : "memory");
+}
+// -> this lane's position on its wavefront's list (meaningful when `need`)
+__device__ __forceinline__ uint32_t mail_post(bool need, RolloutMail& sh, uint32_t q)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, parity = static_cast<int>(q & 1u);
+    if (q >= 2u) mail_wait(&sh.served, q - 1u);          // the lists of q - 2 have been read
+    const uint64_t m = __ballot(need);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    if (need) sh.list[parity][wave][pos] = static_cast<uint8_t>(lane);
+    if (lane == 0) {
+        sh.count[parity][wave] = static_cast<uint32_t>(__builtin_popcountll(m));
+        mail_flag(&sh.posted[wave], q + 1u);
+    }
+    return pos;
+}
+
+template <bool SMALL, typename A>
+__device__ __forceinline__ void mail_serve(const A& a, const StepConst& k, uint64_t tick, int64_t block_first_world, RolloutMail& sh, uint32_t q)
+{
+    constexpr int WAVES = BLOCK_SMALL / 64;
+    const int lane = threadIdx.x & 63, parity = static_cast<int>(q & 1u);
+    uint32_t first[WAVES + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        mail_wait(&sh.posted[w], q + 1u);
+        first[w + 1] = first[w] + sh.count[parity][w];
+    }
+#ifdef AQUA_FUSED_NOSERVE                    // (timing experiment: the protocol without the re-seeding pass)
+    const uint32_t n = 0;
+#else
+    const uint32_t n = uni(first[WAVES]);
+#endif
+    constexpr uint32_t PER_PASS = 64 / RESET_GROUP;
+    for (uint32_t qb = 0; qb < n; qb += PER_PASS) {
+        const uint32_t i = qb + (lane / RESET_GROUP);
+        const bool active = i < n;
+        uint32_t seg = 0;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) seg += (active && i >= first[w]) ? 1u : 0u;
+        const uint32_t at = active ? i - first[seg] : 0u;
+        const uint32_t owner = seg * 64u + sh.list[parity][seg][at];
+        const uint64_t world = static_cast<uint64_t>(a.env_offset + block_first_world) + owner;
+        EnvState f;
+        if constexpr (SMALL)
+            f = reset_env_group<RESET_GROUP, RESEED_QUICK>(active, a.seed, world, tick, k.waves, args_random_boat(a), args_random_goal(a),
+                                                        k.K, k.obst, nullptr, k.quick, k.Kc);
+        else
+            f = reset_env_group<RESET_GROUP>(active, a.seed, world, tick, k.waves, args_random_boat(a), args_random_goal(a), k.K, k.obst);
+        if (active && (lane & (RESET_GROUP - 1)) == 0) {
+            float* r = sh.result[parity][seg * 64u + at];
+            r[0] = f.x; r[1] = f.y; r[2] = f.th; r[3] = f.gx; r[4] = f.gy; r[5] = f.wx; r[6] = f.wy;
+        }
+    }
+    if (lane == 0) mail_flag(&sh.served, q + 1u);
+}
+
+// the fresh states of post q for the lanes that were on its lists (`pos`: what mail_post returned)
+__device__ __forceinline__ void mail_collect(EnvState& e, bool need, uint32_t pos, RolloutMail& sh, uint32_t q)
+{
+    if (!any_lane(need)) return;
+    mail_wait(&sh.served, q + 1u);
+    if (need) {
+        const float* r = sh.result[q & 1u][(threadIdx.x & ~63u) + pos];
+        e.x = r[0]; e.y = r[1]; e.th = r[2]; e.gx = r[3]; e.gy = r[4]; e.wx = r[5]; e.wy = r[6];
+    }
+}
+
 // ------------------------------------------------------------------ one launch per step: no restart, or restart in the same launch
 // Workgroup = TILE_WORLDS lanes, tile = TILE_WORLDS consecutive worlds, one per lane; the per-lane path is the stepping
 // role of step_ns_kernel without the restart markers (same arguments: NsArgs, same addressing; no late loads).
@@ -879,7 +1013,7 @@ struct TileShared {
 template <int AK, bool SMALL_TABLE, bool RESTART, bool WB = false>
 __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
 {
-    tick_housekeeping<NsArgs>();
+    tick_housekeeping(a);
     const uint32_t tile = blockIdx.x * TILE_WORLDS;
     const uint32_t rem = a.N - tile;                   // >= 1
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1009,23 +1143,48 @@ __global__ __launch_bounds__(TILE_WORLDS) void step_kernel(const NsArgs a)
 // SMALL: the table has a quick table (host-selected, as for step_kernel): one inlined copy of the obstacle look and of
 // the re-seeding instead of two behind run-time branches
 // MODE: a.auto_reset, likewise host-selected: one inlined copy of the re-seeding (or none) in the loop
+// the next-step mode's blocks carry a fifth wavefront that owns no worlds and only re-seeds (mail_serve)
+constexpr bool rollout_mail(int mode) { return AQUA_FUSED_MAIL && mode == AQUA_RESET_NEXT_STEP; }
+constexpr int rollout_threads(int mode) { return rollout_mail(mode) ? BLOCK_SMALL + 64 : BLOCK_SMALL; }
 template <int AK, bool SMALL, int MODE>
-__global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs a)     // 4 wavefronts per SIMD: <= 128 VGPRs
+__global__ __launch_bounds__(rollout_threads(MODE), rollout_threads(MODE) / 64) void rollout_kernel(const StepArgs a)   // four blocks per CU
 {
-    __shared__ RolloutShared sh;
+    constexpr bool MAIL = rollout_mail(MODE);
+    __shared__ typename std::conditional<MAIL, RolloutMail, RolloutShared>::type sh;
+    if constexpr (MAIL) {
+        if (threadIdx.x < BLOCK_SMALL / 64) sh.posted[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) sh.served = 0u;
+        __syncthreads();
+    }
     constexpr int QUICK = SMALL ? QUICK_ALWAYS : QUICK_NEVER;
     const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
-    // whole blocks iterate together (barriers inside); lanes past N are inert
+    uint32_t q0 = 0;                                       // posts of this block's earlier tiles (the mailbox's sequence)
+    if constexpr (MAIL) {
+        if (threadIdx.x >= BLOCK_SMALL) {                  // the re-seeding wavefront follows the others through the same tiles
+            if (AQUA_MAIL_PRIO) __builtin_amdgcn_s_setprio(AQUA_MAIL_PRIO);
+            for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
+                 bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL, q0 += static_cast<uint32_t>(a.T))
+                for (int64_t p = 0; p < a.T; ++p)          // post p: the restarts of tick0 + p
+                    mail_serve<SMALL>(a, k, tick0 + static_cast<uint64_t>(p), bbase, sh, q0 + static_cast<uint32_t>(p));
+            return;
+        }
+    }
+    // whole blocks iterate together; lanes past N are inert
     for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
-         bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL) {
+         bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL, q0 += static_cast<uint32_t>(a.T)) {
         const int64_t i = bbase + threadIdx.x;
         const bool valid = i < N;
         const int64_t ic = valid ? i : N - 1;
         EnvState e{a.state[0 * ld + ic], a.state[1 * ld + ic], a.state[2 * ld + ic], a.state[3 * ld + ic],
                    a.state[4 * ld + ic], a.state[5 * ld + ic], a.state[6 * ld + ic], a.time[ic]};
         const uint64_t env = static_cast<uint64_t>(a.env_offset + i);        // the lane's own index (pairs of lanes draw together)
+        // mailbox: `owed` = this lane was on the lists of post (s - 1) -- it did not move during step s - 1 and collects its
+        // fresh state in step s; `posted_pos` = its position on the lists of post s (the worlds that restart DURING step s)
+        bool owed = false;
+        uint32_t owed_pos = 0, posted_pos = 0;
+        if constexpr (MAIL) posted_pos = mail_post(valid && e.t == done_code(tick0 - 1), sh, q0);      // post 0: marked on entry
         for (int64_t s = 0; s < a.T; ++s) {
             const uint64_t tick = tick0 + static_cast<uint64_t>(s);
             const int parity = static_cast<int>(s & 1);
@@ -1037,8 +1196,10 @@ __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs 
                 if (e.t == restart_code(tick - 1)) e.t = 0;
                 restart = valid && e.t == done_code(tick - 1);
                 pending = valid && e.t < 0;
-                tk = publish_reseed(restart, sh, parity);
-                serve_reseed<SMALL>(tk, a, k, tick, bbase, sh, parity);     // one wavefront; the others go on stepping
+                if constexpr (!MAIL) {
+                    tk = publish_reseed(restart, sh, parity);
+                    serve_reseed<SMALL>(tk, a, k, tick, bbase, sh, parity);     // one wavefront; the others go on stepping
+                }
             }
             int idx = 2;
             float vl = 0.5f, vr = 0.5f;
@@ -1056,6 +1217,10 @@ __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs 
                 pair_draws<1, false>(a.seed, env, tick, STREAM_ACT, w0, w1);
                 if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(w0[0]);
                 else { vl = sample_thrust(w0[0]); vr = sample_thrust(w1[0]); }
+            }
+            // the worlds re-seeded during the LAST step move again in this one: their fresh states are due here
+            if constexpr (MAIL) {
+                if (s > 0) mail_collect(e, owed, owed_pos, sh, q0 + static_cast<uint32_t>(s) - 1u);
             }
             if constexpr (AK == AQUA_ACT_BEARING) idx = bearing_action(e.x, e.y, e.th, e.gx, e.gy);
             const Motion m = decode_motion<AK>(k, idx, vl, vr);
@@ -1079,7 +1244,14 @@ __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs 
                 a.term[s * a.out_step_stride + i] = static_cast<uint8_t>(code);
             }
             const bool done = valid && code != 0u;
-            if constexpr (MODE == AQUA_RESET_NEXT_STEP) {
+            if constexpr (MAIL) {
+                if (restart) e.t = restart_code(tick);
+                else if (done) e.t = done_code(tick);
+                owed = restart; owed_pos = posted_pos;
+                // the worlds that restart during step s + 1 (those that just finished; by the marker, which is what step
+                // s + 1 will go by): posted NOW, two steps ahead of their next move
+                if (s + 1 < a.T) posted_pos = mail_post(valid && e.t == done_code(tick), sh, q0 + static_cast<uint32_t>(s) + 1u);
+            } else if constexpr (MODE == AQUA_RESET_NEXT_STEP) {
                 collect_reseed(e, restart, tk, sh);
                 if (restart) e.t = restart_code(tick);
                 else if (done) e.t = done_code(tick);
@@ -1089,6 +1261,7 @@ __global__ __launch_bounds__(BLOCK_SMALL, 4) void rollout_kernel(const StepArgs 
                 collect_reseed(e, done, t1, sh);
             }
         }
+        if constexpr (MAIL) mail_collect(e, owed, owed_pos, sh, q0 + static_cast<uint32_t>(a.T) - 1u);      // the last step's restarts
         if (valid) {
             a.state[0 * ld + i] = e.x; a.state[1 * ld + i] = e.y; a.state[2 * ld + i] = e.th;
             a.state[3 * ld + i] = e.gx; a.state[4 * ld + i] = e.gy;
@@ -1126,11 +1299,28 @@ struct HandoffShared {
     uint8_t world[BLOCK_SMALL / 64][HANDOFF_PER_WAVE];           // the slot's world (offset in the tile)
     ObstF rows[BLOCK_SMALL / 64][HANDOFF_PER_WAVE][KREG];
 };
+// The same hand-off for tables too long for registers (9, 10 and 17..64 rows; next-step restart): a world marked "finished
+// last tick" does not step this tick, but its lane still rides along through the wavefront's coalesced row loads -- it
+// leaves every row in an LDS slot as the loop streams it (fast_step<.., SINK>), and after ONE barrier eight lanes re-seed
+// the world from the slot (reset_env_group<.., RESEED_LDS5>).  What this replaces: the launch split by role, whose
+// re-seeding groups fetched the rows of the worlds their scan found from memory -- one float per 128-byte line, 6 K lines
+// per world, ~5 000 worlds per step: at 64 rows a quarter of a gigabyte of line traffic on top of the 419 MB the step
+// itself streams (262 144 worlds: 98 us per step against 68 without restarts; 32 rows: 48 against 34).
+// SINK_SLOTS slots per wavefront and round (1.2 worlds of a wavefront restart in a step); a wavefront with more takes
+// another round, block-uniform, in which the lanes still waiting read their own rows once more.
+constexpr int SINK_SLOTS = 3;
+struct SinkShared {
+    uint32_t count[BLOCK_SMALL / 64];
+    uint8_t world[BLOCK_SMALL / 64][SINK_SLOTS];                 // the slot's world (offset in the tile)
+    float rows[BLOCK_SMALL / 64][SINK_SLOTS][AQUA_MAX_OBSTACLES * 5];
+};
+struct NoShared {};
 constexpr int TABLES_NEXT_STEP_TILE = 3;
 // MODE: AQUA_RESET_NONE, AQUA_RESET_SAME_STEP (restart inside the launch, below), AQUA_RESET_NEXT_STEP (the stepping
 // role of step_tables_ns_kernel: worlds carrying a restart marker do not step, as in step_ns_kernel),
-// TABLES_NEXT_STEP_TILE (KREG > 0 only: next-step restart inside the tile -- the lane of a world marked "finished last
-// tick" holds that world's rows already and hands them over as the same-step restart does; no re-seeding blocks).
+// TABLES_NEXT_STEP_TILE (next-step restart inside the tile, no re-seeding blocks -- KREG > 0: the lane of a world marked
+// "finished last tick" holds that world's rows already and hands them over as the same-step restart does; KREG == 0: it
+// leaves them in LDS as the row loop streams them, SinkShared above).
 // KREG: tables of at most KREG rows (host-selected; 0: any length).  The lane's rows are then loaded WITH its state --
 // uniform row base + the lane's 32-bit offset, forty loads in flight behind the nine of the state, one memory round trip
 // -- instead of two rows at a time after the move is known (three dependent round trips for eight rows, and 64-bit
@@ -1142,7 +1332,8 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
 {
     constexpr bool RESTART = MODE == AQUA_RESET_SAME_STEP;
     constexpr bool NS = MODE == AQUA_RESET_NEXT_STEP || MODE == TABLES_NEXT_STEP_TILE;
-    static_assert(MODE != TABLES_NEXT_STEP_TILE || KREG > 0, "the in-tile next-step restart hands over rows held in registers");
+    constexpr bool SINK = MODE == TABLES_NEXT_STEP_TILE && KREG == 0;      // rows handed over as they are streamed (SinkShared)
+    __shared__ typename std::conditional<SINK, SinkShared, NoShared>::type ssh;
     const int64_t ld = a.ld, rem = a.N - tile;
     const int lane = threadIdx.x & 63;
     float* const row0 = a.state + tile;
@@ -1209,7 +1400,18 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     const WorldTable wt{t32 + tile, t64 + tile, tld, o};
     float rew;
     uint32_t code;
-    const bool knife = fast_step<true, QUICK_NEVER, KREG>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt, rows) && live;
+    bool sink_want = false;
+    uint32_t sink_mine = 0;
+    uint64_t sink_ballot = 0;
+    float* sink = nullptr;
+    if constexpr (SINK) {
+        sink_want = valid && tin == done_code(tick - 1);          // finished last tick: re-seeded during this one
+        sink_ballot = __ballot(sink_want);
+        sink_mine = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(sink_ballot >> 32),
+                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(sink_ballot), 0u));
+        if (sink_want && sink_mine < SINK_SLOTS) sink = &ssh.rows[threadIdx.x >> 6][sink_mine][0];
+    }
+    const bool knife = fast_step<true, QUICK_NEVER, KREG, SINK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt, rows, sink) && live;
     if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step_world(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.band2,
@@ -1287,6 +1489,59 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             if (uni(most) <= lo + HANDOFF_PER_WAVE) break;        // block-uniform: every wavefront's worlds have had a slot
             __syncthreads();                                      // the slots are written again
         }
+    } else if constexpr (SINK) {
+        constexpr int WAVES = BLOCK_SMALL / 64;
+        const int wave = threadIdx.x >> 6;
+        if (lane == 0) ssh.count[wave] = static_cast<uint32_t>(__builtin_popcountll(sink_ballot));
+        for (uint32_t round = 0;; ++round) {
+            const uint32_t lo = round * SINK_SLOTS;
+            if (sink_want && sink_mine >= lo && sink_mine < lo + SINK_SLOTS) {
+                const uint32_t slot = sink_mine - lo;
+                ssh.world[wave][slot] = static_cast<uint8_t>(threadIdx.x);
+                if (round != 0) {                          // (rare: more than SINK_SLOTS worlds of one wavefront restart at once)
+                    float* const d = &ssh.rows[wave][slot][0];
+#pragma unroll 1
+                    for (int j = 0; j < a.K; ++j) {
+                        const ObstF r = world_row(wt, j);
+                        d[5 * j] = r.cx; d[5 * j + 1] = r.cy; d[5 * j + 2] = r.hx; d[5 * j + 3] = r.hy; d[5 * j + 4] = r.r2;
+                    }
+                }
+            }
+            __syncthreads();
+            uint32_t first[WAVES + 1], most = 0;
+            first[0] = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = ssh.count[w];
+                most = c > most ? c : most;
+                const uint32_t left = c > lo ? c - lo : 0u;
+                first[w + 1] = first[w] + (left < SINK_SLOTS ? left : SINK_SLOTS);
+            }
+            const uint32_t n_round = uni(first[WAVES]);
+            constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+            for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_round; qb += PER_BLOCK) {
+                const uint32_t q = qb + (lane / RESET_GROUP);
+                const bool active = q < n_round;
+                uint32_t seg = 0;
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
+                const uint32_t slot = active ? q - first[seg] : 0u;
+                const uint32_t i = active ? ssh.world[seg][slot] : 0u;                     // an idle group reads a world that exists
+                const WorldTable own{t32 + tile, nullptr, tld, i};
+                const EnvState f = reset_env_group<RESET_GROUP, RESEED_LDS5>(
+                    active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
+                    nullptr, reinterpret_cast<const ObstF*>(&ssh.rows[seg][slot][0]), nullptr, 0, &own);
+                if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                    st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
+                    st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
+                    st1(row0 + 5 * ld + i, f.wx); st1(row0 + 6 * ld + i, f.wy);
+                    st1(trow + i, restart_code(tick));
+                    write_norm(a, tile + i, f.x, f.y, f.th, f.gx, f.gy);
+                }
+            }
+            if (uni(most) <= lo + SINK_SLOTS) break;              // block-uniform: every wavefront's worlds have had a slot
+            __syncthreads();                                      // the slots are written again
+        }
     } else if constexpr (RESTART) {
         // tables of more than eight rows: the groups read their world's rows from memory
         __shared__ TablesShared sh;
@@ -1333,7 +1588,7 @@ __global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 
                                                                   float band2, float band2_tight)
 {
     static_assert(MODE == AQUA_RESET_NONE || MODE == AQUA_RESET_SAME_STEP || MODE == TABLES_NEXT_STEP_TILE, "one tile per block");
-    tick_housekeeping();
+    tick_housekeeping(a);
     tables_step_block<AK, MODE, KREG>(a, t32, t64, tld, band2, band2_tight, static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
 }
 
@@ -1349,7 +1604,7 @@ __global__ __launch_bounds__(NS_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))
                                                                   float band2, float band2_tight)
 {
     __shared__ ResetShared sh;
-    tick_housekeeping();
+    tick_housekeeping(a);
     bool reseed_role;
     uint32_t role;
     if (!ns_role<INTERLEAVE>(static_cast<uint32_t>(a.reseed_blocks), static_cast<uint32_t>((a.N + NS_TILE - 1) / NS_TILE), reseed_role, role)) return;
@@ -2215,7 +2470,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     if (N == 0 || T == 0) return 0;
     a.action = actions; a.action_ld = action_ld; a.action_step_stride = action_step_stride;
     a.reward = reward; a.term = term; a.out_step_stride = out_step_stride; a.T = T; a.auto_reset = auto_reset;
-    const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(BLOCK_SMALL);
+    const dim3 grid(grid_for(N, BLOCK_SMALL, 2048)), block(rollout_threads(auto_reset));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool small = K > 0 && K <= QUICK_MAX;
 #define AQUA_ROLLOUT_MODE(AK, SM)                                                                                         \
@@ -2317,7 +2572,12 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     // next-step restart: tables whose rows are in registers restart inside the tile (rows handed over through LDS); the
     // others keep the launch split by role (their re-seeding groups read the rows from memory)
     const bool ns_tile = a.auto_reset == AQUA_RESET_NEXT_STEP && regs;
-    const bool ns = a.auto_reset == AQUA_RESET_NEXT_STEP && !regs;
+#ifdef AQUA_TABLES_ROLE_SPLIT                 // (A/B timing: round 4's launch split by role for the long tables)
+    const bool ns_sink = false;
+#else
+    const bool ns_sink = a.auto_reset == AQUA_RESET_NEXT_STEP && !regs;     // rows handed over as they are streamed
+#endif
+    const bool ns = a.auto_reset == AQUA_RESET_NEXT_STEP && !regs && !ns_sink;
     const bool interleave = ns && a.N >= NS_INTERLEAVE_MIN;
     int64_t blocks = (a.N + BLOCK_SMALL - 1) / BLOCK_SMALL;
     if (ns) {
@@ -2331,6 +2591,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     case AK:                                                                                                        \
         if (ns_tile && wide) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
         else if (ns_tile) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG>), AQUA_TAB_ARGS);   \
+        else if (ns_sink) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, 0>), AQUA_TAB_ARGS);             \
         else if (regs && wide && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
         else if (regs && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG>), AQUA_TAB_ARGS); \
         else if (regs) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, TABLES_KREG>), AQUA_TAB_ARGS);            \

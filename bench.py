@@ -1172,7 +1172,7 @@ SIMDS = 256 * 4              # MI355X: 256 compute units of four SIMDs (MI355X_M
 
 def issue_bound(n, args, restarts_per_step):
     """(us per launch, source): the vector-issue floor of the benchmarked kernel from the committed instruction budget of
-    the SAME build (profiles/isa_budget.json, written by tools/r04/isa_budget.py from the compiler's own listing): VALU
+    the SAME build (profiles/isa_budget.json, written by tools/isa_budget.py from the compiler's own listing): VALU
     issue cycles of a stepping wavefront x the wavefronts a SIMD steps + those of a re-seeding pass x the passes the
     measured restarts need, / the shader clock.  A launch cannot be shorter than this however its memory traffic goes; the
     HBM figure (`achieved`, `frac`) is the contract's, this is what actually bounds a 262 144-world launch."""

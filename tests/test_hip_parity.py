@@ -870,14 +870,20 @@ def test_per_world_next_step_equals_the_shared_table_kernel(torch):
 
 
 @pytest.mark.parametrize("mode", ["same_step", "next_step"])
-@pytest.mark.parametrize("rows", [8, 11], ids=["rows8_handoff", "rows11_from_memory"])
+@pytest.mark.parametrize("rows", [8, 11, 10, 21, 64], ids=["rows8_handoff", "rows11_handoff16", "rows10_streamed", "rows21_streamed", "rows64_streamed"])
 def test_per_world_restart_of_every_world_at_once(torch, mode, rows):
     """every world of every wavefront restarts in the same step (all past the time limit): the LDS hand-off of the rows
-    (tables of up to 8 rows) then takes eight rounds per tile; == the shared-table kernels bit for bit.  11 rows: the
-    paths that read the rows from memory (role-split launch for the next-step mode)."""
+    (tables of up to 8 rows, 11..16 with restarts) then takes eight rounds per tile; == the shared-table kernels bit for
+    bit.  9, 10 and 17..64 rows: next-step, the rows left in LDS by the lane that streams them (three slots per wavefront:
+    22 rounds here, all but the first with the rows read again by their own lane); same-step, the groups read the rows
+    from memory.  Odd and even lengths (the re-seeding pass tests two rows at a time)."""
     from aquaticgymenv_amd import presets
     n = 3000 + 7
-    base = presets.BENCH8 if rows == 8 else np.concatenate([presets.BENCH8, _obstacle_mix(2, 1, 5)])
+    extra = {8: None, 11: (2, 1), 10: (1, 1), 21: (6, 7), 64: (30, 26)}[rows]
+    base = presets.BENCH8 if extra is None else np.concatenate([presets.BENCH8, _obstacle_mix(extra[0], extra[1], 5)])
+    if rows == 64:
+        base[8:, 3:5] *= 0.3                                     # (64 obstacles of that size would leave no free place)
+    assert base.shape[0] == rows
     tables = np.repeat(base[None], n, axis=0)
     shared = _make(torch, n, base, seed=99, auto_reset=mode)
     mine = _make(torch, n, tables, seed=99, auto_reset=mode)
@@ -1000,6 +1006,60 @@ def test_fused_rollout_equals_stepwise(torch, continuous, mode):
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
     assert (outs[0][3] != 0).sum() > 0
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["same_step", "next_step"])
+@pytest.mark.parametrize("obstacles", ["none", "bench8", "twenty"])
+def test_fused_rollout_in_pieces_equals_stepwise(torch, obstacles, mode):
+    """The fused rollout's restart hand-over (next-step: a wavefront of its own that re-seeds, posts two steps ahead of a
+    world's next move, sequence numbers in LDS -- round 5) at its edges: launches of ONE and TWO steps (no step to post in,
+    the prologue's post and the closing collect only), worlds that come INTO a launch marked done or restarted by the
+    launch before, tables with a quick table (8 rows), without one (20 rows) and none at all, a batch that is not a
+    multiple of the block -- T steps as launches of 1, 2, 1, 5, 3, 20 against 32 launches of the per-step kernel."""
+    from aquaticgymenv_amd import presets
+    rows = {"none": presets.NONE, "bench8": presets.BENCH8,
+            "twenty": np.array([[5.0 + 4.5 * i, 8.0 + 4.2 * ((7 * i) % 20), i % 2, 2.0 + (i % 3), 1.5 + (i % 2)] for i in range(20)])}[obstacles]
+    n, pieces = 5000 + 7, [1, 2, 1, 5, 3, 20]
+    T = sum(pieces)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.randint(0, 3, (T, (n + 63) // 64 * 64), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+    ref = _make(torch, n, rows, seed=17, auto_reset=mode, env_offset=128)
+    ref.reset()
+    ref.time[:n] = torch.randint(0, 1001, (n,), device="cuda", generator=g).to(torch.int32)      # time-outs among the endings
+    fused = _make(torch, n, rows, seed=17, auto_reset=mode, env_offset=128)
+    fused.reset()
+    fused.time.copy_(ref.time)
+    want_r, want_c = ref.rollout(T, actions=acts, fused=False)
+    t0, restarts = 0, 0
+    for piece in pieces:
+        r, c = fused.rollout(piece, actions=acts[t0:t0 + piece], fused=True)
+        assert torch.equal(r[:, :n], want_r[t0:t0 + piece, :n]) and torch.equal(c[:, :n], want_c[t0:t0 + piece, :n]), \
+            "the launch of steps [%d, %d) differs" % (t0, t0 + piece)
+        restarts += int((c[:, :n] != 0).sum())
+        t0 += piece
+    assert torch.equal(fused.state, ref.state) and torch.equal(fused.time, ref.time) and fused._tick == ref._tick == T
+    assert restarts > 100
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["same_step", "next_step"])
+def test_fused_rollout_of_blocks_that_walk_several_tiles(torch, mode):
+    """more than 2 048 x 256 worlds: the fused rollout's grid is capped, every block walks two or three tiles of 256 worlds
+    one after the other (the mailbox's sequence numbers run on across the tiles) -- against the per-step kernels, actions
+    sampled on the device"""
+    from aquaticgymenv_amd import presets
+    n, T = 2048 * 256 * 2 + 5000, 12
+    outs = []
+    for fused in (False, True):
+        env = _make(torch, n, presets.BENCH8, seed=23, auto_reset=mode)
+        env.reset()
+        env.time[:n] = 995                                    # everybody times out inside the rollout: whole wavefronts restart
+        reward, term = env.rollout(T, actions="random", fused=fused)
+        torch.cuda.synchronize()
+        outs.append((env.state.clone(), env.time.clone(), reward[:, :n].clone(), term[:, :n].clone()))
+        del env
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert int((outs[0][3] != 0).sum()) >= n
 
 
 @pytest.mark.parametrize("T", [1, 2, 16], ids=["one_step_graph", "two_step_graph", "sixteen_step_graph"])

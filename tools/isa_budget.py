@@ -22,7 +22,7 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 QUARTER = re.compile(r"^v_(mad_u64_u32|mad_i64_i32|mul_lo_u32|mul_hi_u32|mul_hi_i32|mul_lo_i32|sin_f32|cos_f32|sqrt_f32|rcp_f32|"
                      r"rsq_f32|exp_f32|log_f32|rcp_f64|rsq_f64|sqrt_f64|div_fixup_f64|div_fmas_f64|div_scale_f64)")
 HALF = re.compile(r"^v_(\w+_f64|lshlrev_b64|lshrrev_b64|ashrrev_i64|mul_f64|fma_f64|add_f64)")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r04/isa/ + profiles/isa_budget.json for the CURRENT build of the benchmarked kernel (no GPU needed).
+"""profiles/<round>/isa/ (AQUA_PROFILE_ROUND, default r05) + profiles/isa_budget.json for the CURRENT build of the benchmarked kernel (no GPU needed).
 
     make_isa_budget.py <key> <mangled-name substring> stepping=<blocks> stepping_late=<blocks> reseed_pass=<blocks> [...]
 
@@ -9,7 +9,7 @@
                   stepping_late  one that issues them behind its draws (wavefronts 1-3)
                   reseed_pass    one pass of a re-seeding wavefront over its (up to eight) worlds, scan and compaction included
 Writes the kernel's listing (<key>.s), its block table (<key>.blocks.txt), the per-path counts (<key>.budget.json) under
-profiles/r04/isa/ and the row bench.py reads (valu issue cycles per stepping wavefront = the average of the two stepping
+profiles/<round>/isa/ and the row bench.py reads (valu issue cycles per stepping wavefront = the average of the two stepping
 paths weighted 1 : 3; per re-seeding pass) into profiles/isa_budget.json, tagged with the library's hash.
 """
 import hashlib
@@ -18,9 +18,10 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-TOOL = os.path.join(ROOT, "tools", "r04", "isa_budget.py")
-OUT = os.path.join(ROOT, "profiles", "r04", "isa")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "isa_budget.py")
+ROUND = os.environ.get("AQUA_PROFILE_ROUND", "r05")          # the listing and counts go to profiles/<round>/isa/
+OUT = os.path.join(ROOT, "profiles", ROUND, "isa")
 
 
 def main(argv):
@@ -42,7 +43,7 @@ def main(argv):
     with open(os.path.join(OUT, key + ".budget.json"), "w") as f:
         json.dump(counts, f, indent=1, sort_keys=True)
     early, late = counts["stepping"]["valu_issue_cycles"], counts.get("stepping_late", counts["stepping"])["valu_issue_cycles"]
-    row = {"library_sha16": tag, "source": "profiles/r04/isa/%s.budget.json" % key, "kernel": name,
+    row = {"library_sha16": tag, "source": "profiles/%s/isa/%s.budget.json" % (ROUND, key), "kernel": name,
            "valu_cycles_stepping_wavefront": 0.25 * early + 0.75 * late,
            "valu_cycles_reseed_pass": counts["reseed_pass"]["valu_issue_cycles"],
            "valu_instructions_stepping_wavefront": 0.25 * (counts["stepping"].get("valu", 0) + counts["stepping"].get("lane", 0))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the benchmarked kernel (configs[2], next-step restart), three passes of <= 8 counters:
-#   tools/r04/pmc_sq.sh <tag under gpurun_out> [bench args]
+#   tools/pmc_sq.sh <tag under gpurun_out> [bench args]
 # rocprofv3 gets the program itself after "--"; --pmc passes carry --kernel-trace only (no other trace domain)
 set -u
 TAG=$1; shift
