@@ -403,9 +403,19 @@ __device__ __noinline__ ExactOut exact_step_impl(float fx, float fy, float fth, 
 
     bool hit = (nx - 2.5 < 0.0) || (ny - 2.5 < 0.0) || (nx + 2.5 > 100.0) || (ny + 2.5 > 100.0);
     const float xs = static_cast<float>(nx), ys = static_cast<float>(ny);
+    constexpr int XL = PER_WORLD ? 4 : 1;                  // per-world rows come from memory: four per round trip (as the second look)
+    ObstF chunk[XL];
     for (int k = 0; k < K; ++k) {
         ObstF row;
-        if constexpr (PER_WORLD) row = world_row(wt, k);
+        if constexpr (PER_WORLD) {
+            if (k % XL == 0) {
+#pragma unroll
+                for (int u = 0; u < XL; ++u) chunk[u] = world_row(wt, k + u < K ? k + u : K - 1);
+            }
+            row = chunk[0];
+#pragma unroll
+            for (int u = 1; u < XL; ++u) if (k % XL == u) row = chunk[u];
+        }
         else { row.cx = obst32[k].cx; row.cy = obst32[k].cy; row.hx = obst32[k].hx; row.hy = obst32[k].hy; row.r2 = obst32[k].r2; }
         const float bx = fmaxf(fabsf(xs - row.cx) - row.hx, 0.0f);
         const float by = fmaxf(fabsf(ys - row.cy) - row.hy, 0.0f);
@@ -501,6 +511,21 @@ __device__ __forceinline__ float quick_min(float mo, float xn, float yn, const Q
 // QUICK: the first look reads the quick table (k.qc0, k.qr0, k.quick) instead of walking the rows --
 // QUICK_ALWAYS: the caller knows the table has one; QUICK_IF_PRESENT: when k.quick is not NULL (wave-uniform).
 enum : int { QUICK_NEVER = 0, QUICK_ALWAYS = 1, QUICK_IF_PRESENT = 2 };
+// INFLIGHT (PER_WORLD with KREG == 0): rows of its table a lane has in flight while it streams them.  The loop is bound by
+// memory latency x loads in flight per SIMD: the no-restart kernel runs seven wavefronts per SIMD on 71 registers and reaches
+// the copy bandwidth with two rows in flight; the restart kernels carry the re-seeding code's 91-95 registers (five
+// wavefronts per SIMD) and ran at exactly 5/7 of its rate -- "the restart's cost" of rounds 3 and 4 (64 rows: 98 against 70
+// us per step) was this, not the re-seeding.  They have the registers for more rows in flight at no cost in occupancy.
+#ifndef AQUA_SECOND_LOOK_ROWS
+#define AQUA_SECOND_LOOK_ROWS 8
+#endif
+#ifndef AQUA_SECOND_LOOK_ROWS_KREG
+#define AQUA_SECOND_LOOK_ROWS_KREG 4
+#endif
+constexpr int SECOND_LOOK_ROWS = AQUA_SECOND_LOOK_ROWS, SECOND_LOOK_ROWS_KREG = AQUA_SECOND_LOOK_ROWS_KREG;   // (fast_step's second look)
+#ifndef AQUA_TABLE_ROWS_IN_FLIGHT_RESTART
+#define AQUA_TABLE_ROWS_IN_FLIGHT_RESTART 4
+#endif
 // KREG > 0 (PER_WORLD only): the caller has read the lane's first KREG rows into registers (`regs`, loaded with the
 // state, one memory round trip for everything; rows past the table's end repeat its last row, which leaves a minimum
 // unchanged) and the first look is arithmetic only; the second look and the float64 path (rare) still read `wt`.
@@ -508,7 +533,7 @@ enum : int { QUICK_NEVER = 0, QUICK_ALWAYS = 1, QUICK_IF_PRESENT = 2 };
 // sink[5 j .. 5 j + 4] (cx, cy, hx, hy, r2; an LDS slot of the caller's) -- the rows of a world that restarts this tick,
 // for the lanes that re-seed it (reset_env_group<.., RESEED_LDS5>): they ride along with the wavefront's own coalesced row
 // loads instead of being fetched again, one 128-byte line per float, by the re-seeding group.
-template <bool PER_WORLD = false, int QUICK = QUICK_NEVER, int KREG = 0, bool SINK = false>
+template <bool PER_WORLD = false, int QUICK = QUICK_NEVER, int KREG = 0, bool SINK = false, int INFLIGHT = 2>
 __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float chord, float u0, float u1,
                                           const StepConst& k, float& reward, uint32_t& term, const WorldTable* wt = nullptr,
                                           const ObstF* regs = nullptr, float* sink = nullptr)
@@ -535,7 +560,7 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
             mo = fminf(mo, fmaf(dx, dx, fmaf(dy, dy, -regs[j].r2)));
         }
     } else if constexpr (PER_WORLD) {
-#pragma unroll 2
+#pragma unroll INFLIGHT
         for (int j = 0; j < k.K; ++j) {                    // a circle is a box with zero half extents: same bits
             const ObstF r = world_row(*wt, j);
             if constexpr (SINK) {
@@ -601,14 +626,25 @@ __device__ __forceinline__ bool fast_step(EnvState& e, float h, float w, float c
         // band of THAT obstacle's radius, 2.5 (R + BAND) BAND_TIGHT + 4 ulp(R^2) -- not R_max's, which for the
         // R = 2.5 of every rectangle would be several times wider than its own in distance.
         if constexpr (PER_WORLD) {
-            // a cold path (a few per cent of the wavefronts): one row at a time.  Unrolled, the compiler keeps forty
-            // loads and their addresses in flight here and this loop alone sets the kernel's register count (156-187)
+            // A cold path -- a wavefront in two hundred takes it -- but one that ENDS the launch: every wavefront of a
+            // streaming launch reaches this point at about the same time, so the launch lasts as long as the slowest second
+            // look.  One row at a time (rounds 1-4: the loop was kept out of the kernel's register count) that was K
+            // dependent memory round trips at the tail of EVERY launch -- 13 of the 70 us of a 64-row step, 1.5 of the 10 us
+            // of an 8-row one.  Now SECOND_LOOK_ROWS rows per round trip; a row index past the table repeats its last row,
+            // which leaves a minimum unchanged.  (The registers are there: capping these kernels at five or four wavefronts
+            // per SIMD changes nothing, profiles/r05/tables/.)
+            constexpr int SL = KREG == 0 ? SECOND_LOOK_ROWS : SECOND_LOOK_ROWS_KREG;
 #pragma unroll 1
-            for (int j = 0; j < k.K; ++j) {
-                const ObstF r = world_row(*wt, j);
-                const float dx = fmaxf(fabsf((xn - r.cx) + xlo) - r.hx, 0.0f);
-                const float dy = fmaxf(fabsf((yn - r.cy) + ylo) - r.hy, 0.0f);
-                mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -r.r2)) * r.w);
+            for (int j0 = 0; j0 < k.K; j0 += SL) {
+                ObstF r[SL];
+#pragma unroll
+                for (int u = 0; u < SL; ++u) r[u] = world_row(*wt, j0 + u < k.K ? j0 + u : k.K - 1);
+#pragma unroll
+                for (int u = 0; u < SL; ++u) {
+                    const float dx = fmaxf(fabsf((xn - r[u].cx) + xlo) - r[u].hx, 0.0f);
+                    const float dy = fmaxf(fabsf((yn - r[u].cy) + ylo) - r[u].hy, 0.0f);
+                    mo2 = fminf(mo2, fmaf(dx, dx, fmaf(dy, dy, -r[u].r2)) * r[u].w);
+                }
             }
         } else {
         for (int j = 0; j < k.Kc; ++j) {
@@ -915,14 +951,30 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 hit_b = ((mb >> sub) & every) != 0ull;
             }
         } else if constexpr (ROWS == RESEED_LDS5) {
+            // SOA_SPLIT > 1 (as for RESEED_SOA): the world is re-seeded by SOA_SPLIT groups of G lanes side by side, every
+            // group makes the same G attempts against its own share of the rows (pairs of rows dealt round robin), and the
+            // hits are OR-ed across the groups before anything is decided: the pass over a long table -- the tail of its
+            // block, and with all blocks resident of the launch -- is SOA_SPLIT times shorter
+            static_assert(SOA_SPLIT >= 1 && G * SOA_SPLIT <= 64, "whole groups");
             const float* const slot = reinterpret_cast<const float*>(rows);
+            const int share = SOA_SPLIT > 1 ? (lane & (G * SOA_SPLIT - 1)) / G : 0;
 #pragma unroll 1
-            for (int j = 0; j < K; j += 2) {             // two rows in registers; an odd K tests its last row twice
+            for (int j = 2 * share; j < K; j += 2 * SOA_SPLIT) {       // two rows in registers; an odd K tests its last row twice
                 const float* const r0 = slot + 5 * j;
                 const float* const r1 = slot + 5 * (j + 1 < K ? j + 1 : j);
                 const float c0[5] = {r0[0], r0[1], r0[2], r0[3], r0[4]}, c1[5] = {r1[0], r1[1], r1[2], r1[3], r1[4]};
                 test(c0[0], c0[1], c0[2], c0[3], c0[4]);
                 test(c1[0], c1[1], c1[2], c1[3], c1[4]);
+            }
+            if constexpr (SOA_SPLIT > 1) {                 // a candidate is hit if any group's share of the rows hits it
+                constexpr int GW = G * SOA_SPLIT;
+                uint64_t every = 0;                        // bit 0 of every group of the world
+#pragma unroll
+                for (int c = 0; c < SOA_SPLIT; ++c) every |= 1ull << (c * G);
+                const int wbase = lane & ~(GW - 1);
+                const uint64_t mg = __ballot(hit_g) >> wbase, mb = __ballot(hit_b) >> wbase;
+                hit_g = ((mg >> sub) & every) != 0ull;
+                hit_b = ((mb >> sub) & every) != 0ull;
             }
         } else if constexpr (ROWS == RESEED_WORLD) {
 #pragma unroll 1

@@ -889,8 +889,11 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 #define AQUA_MAIL_SPIN_LIMIT (1u << 18)                    // polls of ~0.1 us; a wait that is answered takes a few
 #endif
 constexpr uint32_t MAIL_SPIN_LIMIT = AQUA_MAIL_SPIN_LIMIT;
+// the re-seeding wavefront runs at raised priority: its pass is one long dependent chain, and the four stepping wavefronts it
+// shares a SIMD with would otherwise leave it a fifth of the issue slots (262 144 worlds, next-step restarts, us per step:
+// priority 0 4.22, 1 3.52, 2 3.48-3.58, 3 3.50-3.52; the barrier protocol 4.01-4.03 -- profiles/r05/fused_mail/)
 #ifndef AQUA_MAIL_PRIO
-#define AQUA_MAIL_PRIO 0
+#define AQUA_MAIL_PRIO 2
 #endif
 struct RolloutMail {
     uint32_t posted[BLOCK_SMALL / 64];
@@ -1308,7 +1311,13 @@ struct HandoffShared {
 // itself streams (262 144 worlds: 98 us per step against 68 without restarts; 32 rows: 48 against 34).
 // SINK_SLOTS slots per wavefront and round (1.2 worlds of a wavefront restart in a step); a wavefront with more takes
 // another round, block-uniform, in which the lanes still waiting read their own rows once more.
-constexpr int SINK_SLOTS = 3;
+#ifndef AQUA_SINK_SLOTS
+#define AQUA_SINK_SLOTS 3
+#endif
+constexpr int SINK_SLOTS = AQUA_SINK_SLOTS;
+// groups of eight lanes per restarting world (tables_step_block's SINK_SPLIT; 262 144 worlds, next-step, us per step with 1 /
+// 2 / 4: 9 rows 16.5 / 16.6 / 17.3, 17 rows 24.7 / 24.7 / 24.5, 32 rows 40.2 / 38.8 / 37.5, 64 rows 81.2 / 76.5 / 75.6)
+constexpr int SINK_SPLIT_SHORT = 2, SINK_SPLIT_LONG = 4, SINK_SPLIT_LONG_MIN_ROWS = 24;
 struct SinkShared {
     uint32_t count[BLOCK_SMALL / 64];
     uint8_t world[BLOCK_SMALL / 64][SINK_SLOTS];                 // the slot's world (offset in the tile)
@@ -1326,14 +1335,23 @@ constexpr int TABLES_NEXT_STEP_TILE = 3;
 // -- instead of two rows at a time after the move is known (three dependent round trips for eight rows, and 64-bit
 // per-lane addresses that cost the kernel 187 registers: two wavefronts per SIMD).
 constexpr int TABLES_KREG = 8, TABLES_KREG_WIDE = 16, TABLES_KREG_WIDE_MIN = 11;      // (HandoffShared<KREG>)
-template <int AK, int MODE, int KREG>
+template <int AK, int MODE, int KREG, int SINK_SPLIT = 2>
 __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float* __restrict__ t32, const double* __restrict__ t64,
                                                   int64_t tld, float band2, float band2_tight, int64_t tile)
 {
     constexpr bool RESTART = MODE == AQUA_RESET_SAME_STEP;
     constexpr bool NS = MODE == AQUA_RESET_NEXT_STEP || MODE == TABLES_NEXT_STEP_TILE;
     constexpr bool SINK = MODE == TABLES_NEXT_STEP_TILE && KREG == 0;      // rows handed over as they are streamed (SinkShared)
-    __shared__ typename std::conditional<SINK, SinkShared, NoShared>::type ssh;
+    // Same-step restart of such tables: which worlds finish is known only after the rows have gone by.  Fetching a finished
+    // world's rows again cooperatively into the same slots (REFETCH) was built and measured: 64 rows 95 -> 107-112 us per
+    // step, 32 rows 48.7 -> 49-50 (rounds of three worlds per wavefront, a barrier and a fetch each, where the groups that
+    // read their rows from memory all work at once) -- off, the code path is kept for the A/B (-DAQUA_TABLES_REFETCH)
+#ifdef AQUA_TABLES_REFETCH
+    constexpr bool REFETCH = MODE == AQUA_RESET_SAME_STEP && KREG == 0;
+#else
+    constexpr bool REFETCH = false;
+#endif
+    __shared__ typename std::conditional<SINK || REFETCH, SinkShared, NoShared>::type ssh;
     const int64_t ld = a.ld, rem = a.N - tile;
     const int lane = threadIdx.x & 63;
     float* const row0 = a.state + tile;
@@ -1411,7 +1429,8 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(sink_ballot), 0u));
         if (sink_want && sink_mine < SINK_SLOTS) sink = &ssh.rows[threadIdx.x >> 6][sink_mine][0];
     }
-    const bool knife = fast_step<true, QUICK_NEVER, KREG, SINK>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt, rows, sink) && live;
+    constexpr int INFLIGHT = MODE == AQUA_RESET_NONE ? 2 : AQUA_TABLE_ROWS_IN_FLIGHT_RESTART;       // (see fast_step)
+    const bool knife = fast_step<true, QUICK_NEVER, KREG, SINK, INFLIGHT>(e, mo.h, mo.w, mo.chord, u0[0], u1[0], k, rew, code, &wt, rows, sink) && live;
     if (__builtin_expect(any_lane(knife), 0)) {
         if (knife) {
             const ExactOut o2 = exact_step_world(x0, y0, th0, gx[0], gy[0], wx0, wy0, e.t, exact_motion<AK>(mo), k.K, k.band2,
@@ -1489,21 +1508,33 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
             if (uni(most) <= lo + HANDOFF_PER_WAVE) break;        // block-uniform: every wavefront's worlds have had a slot
             __syncthreads();                                      // the slots are written again
         }
-    } else if constexpr (SINK) {
+    } else if constexpr (SINK || REFETCH) {
         constexpr int WAVES = BLOCK_SMALL / 64;
         const int wave = threadIdx.x >> 6;
+        if constexpr (REFETCH) {                                   // the worlds that finished in this step
+            sink_want = done;
+            sink_ballot = done_ballot;
+            sink_mine = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(sink_ballot >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(sink_ballot), 0u));
+        }
         if (lane == 0) ssh.count[wave] = static_cast<uint32_t>(__builtin_popcountll(sink_ballot));
         for (uint32_t round = 0;; ++round) {
             const uint32_t lo = round * SINK_SLOTS;
-            if (sink_want && sink_mine >= lo && sink_mine < lo + SINK_SLOTS) {
-                const uint32_t slot = sink_mine - lo;
-                ssh.world[wave][slot] = static_cast<uint8_t>(threadIdx.x);
-                if (round != 0) {                          // (rare: more than SINK_SLOTS worlds of one wavefront restart at once)
-                    float* const d = &ssh.rows[wave][slot][0];
+            if (sink_want && sink_mine >= lo && sink_mine < lo + SINK_SLOTS) ssh.world[wave][sink_mine - lo] = static_cast<uint8_t>(threadIdx.x);
+            if (round != 0 || REFETCH) {
+                // more than SINK_SLOTS worlds of this wavefront restart at once (one wavefront in eight at 64 rows): the worlds
+                // still waiting have their rows fetched by the WHOLE wavefront, lane j row j -- 5 loads per lane, all in flight,
+                // one memory round trip (left to the owning lane alone it was K dependent round trips at the block's tail)
+                static_assert(AQUA_MAX_OBSTACLES <= 64, "one row per lane");
 #pragma unroll 1
-                    for (int j = 0; j < a.K; ++j) {
-                        const ObstF r = world_row(wt, j);
-                        d[5 * j] = r.cx; d[5 * j + 1] = r.cy; d[5 * j + 2] = r.hx; d[5 * j + 3] = r.hy; d[5 * j + 4] = r.r2;
+                for (uint32_t sl = 0; sl < SINK_SLOTS; ++sl) {
+                    const uint64_t who = __ballot(sink_want && sink_mine == lo + sl);
+                    if (who == 0) break;                                                    // wavefront-uniform
+                    const uint32_t owner = (threadIdx.x & ~63u) + static_cast<uint32_t>(__builtin_ctzll(who));
+                    if (lane < a.K) {
+                        const ObstF r = world_row(WorldTable{t32 + tile, nullptr, tld, owner}, lane);
+                        float* const d = &ssh.rows[wave][sl][5 * lane];
+                        d[0] = r.cx; d[1] = r.cy; d[2] = r.hx; d[3] = r.hy; d[4] = r.r2;
                     }
                 }
             }
@@ -1518,9 +1549,12 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
                 first[w + 1] = first[w] + (left < SINK_SLOTS ? left : SINK_SLOTS);
             }
             const uint32_t n_round = uni(first[WAVES]);
-            constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+            // SINK_SPLIT groups of eight lanes per world, each with its share of the rows (reset_env_group): a round holds at
+            // most WAVES * SINK_SLOTS = 12 worlds, the block's 256 lanes are 32 groups -- without the split two wavefronts in
+            // three sat out the pass that the whole block waits for
+            constexpr uint32_t LANES = RESET_GROUP * SINK_SPLIT, PER_WAVE = 64 / LANES, PER_BLOCK = WAVES * PER_WAVE;
             for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_round; qb += PER_BLOCK) {
-                const uint32_t q = qb + (lane / RESET_GROUP);
+                const uint32_t q = qb + (lane / LANES);
                 const bool active = q < n_round;
                 uint32_t seg = 0;
 #pragma unroll
@@ -1528,14 +1562,14 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
                 const uint32_t slot = active ? q - first[seg] : 0u;
                 const uint32_t i = active ? ssh.world[seg][slot] : 0u;                     // an idle group reads a world that exists
                 const WorldTable own{t32 + tile, nullptr, tld, i};
-                const EnvState f = reset_env_group<RESET_GROUP, RESEED_LDS5>(
+                const EnvState f = reset_env_group<RESET_GROUP, RESEED_LDS5, 8, 256, SINK_SPLIT>(
                     active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
                     nullptr, reinterpret_cast<const ObstF*>(&ssh.rows[seg][slot][0]), nullptr, 0, &own);
-                if (active && (lane & (RESET_GROUP - 1)) == 0) {
+                if (active && (lane & (LANES - 1)) == 0) {
                     st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
                     st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
                     st1(row0 + 5 * ld + i, f.wx); st1(row0 + 6 * ld + i, f.wy);
-                    st1(trow + i, restart_code(tick));
+                    st1(trow + i, REFETCH ? f.t : restart_code(tick));
                     write_norm(a, tile + i, f.x, f.y, f.th, f.gx, f.gy);
                 }
             }
@@ -1582,14 +1616,17 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
 // (registers: 78-114 by instantiation; the attribute only states the floor of two wavefronts per SIMD.  Asking for more
 // makes the compiler spill to scratch; what brought the count down from 187-242 was not unrolling the cold loops,
 // aqua_device.hpp)
-template <int AK, int MODE, int KREG>
-__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
+#ifndef AQUA_TABLES_MAX_WAVES                // (timing experiment: the no-restart kernel at the restart kernels' occupancy)
+#define AQUA_TABLES_MAX_WAVES 8
+#endif
+template <int AK, int MODE, int KREG, int SINK_SPLIT = SINK_SPLIT_SHORT>
+__global__ __launch_bounds__(BLOCK_SMALL) __attribute__((amdgpu_waves_per_eu(2, AQUA_TABLES_MAX_WAVES))) void step_tables_kernel(const StepArgs a, const float* __restrict__ t32,
                                                                   const double* __restrict__ t64, int64_t tld,
                                                                   float band2, float band2_tight)
 {
     static_assert(MODE == AQUA_RESET_NONE || MODE == AQUA_RESET_SAME_STEP || MODE == TABLES_NEXT_STEP_TILE, "one tile per block");
     tick_housekeeping(a);
-    tables_step_block<AK, MODE, KREG>(a, t32, t64, tld, band2, band2_tight, static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
+    tables_step_block<AK, MODE, KREG, SINK_SPLIT>(a, t32, t64, tld, band2, band2_tight, static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL);
 }
 
 // Next-step restart with per-world tables: step_ns_kernel's launch split by role (same markers in the time row, same
@@ -2591,6 +2628,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
     case AK:                                                                                                        \
         if (ns_tile && wide) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
         else if (ns_tile) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, TABLES_KREG>), AQUA_TAB_ARGS);   \
+        else if (ns_sink && a.K >= SINK_SPLIT_LONG_MIN_ROWS) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, 0, SINK_SPLIT_LONG>), AQUA_TAB_ARGS); \
         else if (ns_sink) hipLaunchKernelGGL((step_tables_kernel<AK, TABLES_NEXT_STEP_TILE, 0>), AQUA_TAB_ARGS);             \
         else if (regs && wide && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG_WIDE>), AQUA_TAB_ARGS); \
         else if (regs && a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, TABLES_KREG>), AQUA_TAB_ARGS); \

@@ -199,9 +199,9 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
  * and returns the largest collision radius of the batch in *r_max (sizes the knife-edge bands).
  *
  * aqua_step_tables_f32 / aqua_rollout_tables_f32 / aqua_reset_tables_f32 are aqua_step_f32 / aqua_rollout_f32 /
- * aqua_reset_f32 with these tables: every restart mode (AQUA_RESET_NEXT_STEP keeps the same markers in time[]; tables of up
- * to 8 rows restart inside the stepping tile, the world's own lane handing its rows to the re-seeding lanes through LDS,
- * longer ones use the launch split by role), every action kind, and all other arguments mean what they mean there.  Results for a batch whose
+ * aqua_reset_f32 with these tables: every restart mode (AQUA_RESET_NEXT_STEP keeps the same markers in time[]; a finished world
+ * restarts inside the stepping tile, its own lane handing its rows to the re-seeding lanes through LDS -- from registers
+ * for tables of up to 16 rows, as the row loop streams them for longer ones), every action kind, and all other arguments mean what they mean there.  Results for a batch whose
  * worlds all hold the same list are bit-identical to the shared-table calls.  Algorithmic bytes per world-step:
  * 62 + 24 K (discrete).
  */
