@@ -977,11 +977,34 @@ __device__ __forceinline__ EnvState reset_env_group(bool active, uint64_t seed, 
                 hit_b = ((mb >> sub) & every) != 0ull;
             }
         } else if constexpr (ROWS == RESEED_WORLD) {
+            if constexpr (SOA_SPLIT > 1) {
+                // SOA_SPLIT groups per world, four rows per round trip each (as RESEED_LDS5's split, but the rows come from
+                // memory): K / (4 SOA_SPLIT) dependent round trips at the block's tail instead of K / 2
+                static_assert(G * SOA_SPLIT <= 64, "whole groups");
+                const int share = (lane & (G * SOA_SPLIT - 1)) / G;
+#pragma unroll 1
+                for (int j = 4 * share; j < K; j += 4 * SOA_SPLIT) {
+                    ObstF r[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r[u] = world_row(*wt, j + u < K ? j + u : K - 1);     // (a repeated row changes no OR)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) test(r[u].cx, r[u].cy, r[u].hx, r[u].hy, r[u].r2);
+                }
+                constexpr int GW = G * SOA_SPLIT;
+                uint64_t every = 0;
+#pragma unroll
+                for (int c = 0; c < SOA_SPLIT; ++c) every |= 1ull << (c * G);
+                const int wbase = lane & ~(GW - 1);
+                const uint64_t mg = __ballot(hit_g) >> wbase, mb = __ballot(hit_b) >> wbase;
+                hit_g = ((mg >> sub) & every) != 0ull;
+                hit_b = ((mb >> sub) & every) != 0ull;
+            } else {
 #pragma unroll 1
             for (int j = 0; j < K; j += 2) {             // two rows in flight; an odd K tests its last row twice
                 const ObstF r0 = world_row(*wt, j), r1 = world_row(*wt, j + 1 < K ? j + 1 : j);
                 test(r0.cx, r0.cy, r0.hx, r0.hy, r0.r2);
                 test(r1.cx, r1.cy, r1.hx, r1.hy, r1.r2);
+            }
             }
         } else if constexpr (ROWS == RESEED_QUICK) {
             const auto circles = [&](const QuickCircles& g) {

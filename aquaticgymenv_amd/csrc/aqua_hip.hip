@@ -1590,19 +1590,21 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) first[w + 1] = first[w] + sh.count[w];
         const uint32_t n_done = uni(first[WAVES]);
-        constexpr uint32_t PER_WAVE = 64 / RESET_GROUP, PER_BLOCK = WAVES * PER_WAVE;
+        // SINK_SPLIT groups of eight lanes per world here too (see RESEED_WORLD): ~8 worlds of a tile finish in a step, the
+        // block's 256 lanes are 32 groups
+        constexpr uint32_t LANES = RESET_GROUP * SINK_SPLIT, PER_WAVE = 64 / LANES, PER_BLOCK = WAVES * PER_WAVE;
         for (uint32_t qb = static_cast<uint32_t>(wave) * PER_WAVE; qb < n_done; qb += PER_BLOCK) {
-            const uint32_t q = qb + (lane / RESET_GROUP);
+            const uint32_t q = qb + (lane / LANES);
             const bool active = q < n_done;
             uint32_t seg = 0;
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) seg += (active && q >= first[w]) ? 1u : 0u;
             const uint32_t i = active ? sh.list[seg][q - first[seg]] : 0u;             // an idle group reads a world that exists
             const WorldTable own{t32 + tile, nullptr, tld, i};
-            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD>(
+            const EnvState f = reset_env_group<RESET_GROUP, RESEED_WORLD, 8, 256, SINK_SPLIT>(
                 active, a.seed, static_cast<uint64_t>(a.env_offset + tile) + i, tick, a.waves, a.random_boat, a.random_goal, a.K,
                 nullptr, nullptr, nullptr, 0, &own);
-            if (active && (lane & (RESET_GROUP - 1)) == 0) {
+            if (active && (lane & (LANES - 1)) == 0) {
                 st1(row0 + 0 * ld + i, f.x); st1(row0 + 1 * ld + i, f.y); st1(row0 + 2 * ld + i, f.th);
                 st1(row0 + 3 * ld + i, f.gx); st1(row0 + 4 * ld + i, f.gy);
                 st1(row0 + 5 * ld + i, f.wx); st1(row0 + 6 * ld + i, f.wy);
@@ -2635,6 +2637,7 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
         else if (regs) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, TABLES_KREG>), AQUA_TAB_ARGS);            \
         else if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true>), AQUA_TAB_ARGS);                           \
         else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false>), AQUA_TAB_ARGS);                                  \
+        else if (a.auto_reset && a.K >= SINK_SPLIT_LONG_MIN_ROWS) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0, SINK_SPLIT_LONG>), AQUA_TAB_ARGS); \
         else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0>), AQUA_TAB_ARGS);         \
         else hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, 0>), AQUA_TAB_ARGS);                                \
         break;

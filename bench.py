@@ -129,6 +129,9 @@ def parse(argv=None):
                     help="seconds all extra legs together may take: past it rank 0 prints the line with what it has and "
                          "extras.exchange_ab.error naming the stage, and every rank exits with status 0 (the main line is "
                          "never lost to an optional leg)")
+    ap.add_argument("--teardown-deadline", type=float, default=60.0,
+                    help="N > 1: seconds the collective tear-down behind the printed line may take before every rank still in "
+                         "it exits with status 0")
     ap.add_argument("--extras", action="store_true", help="also time the fused rollout kernel (separate line)")
     ap.add_argument("--per-world-tables", action="store_true",
                     help="separate line (extras.per_world_tables): every world has its own 8-obstacle list")
@@ -1094,6 +1097,10 @@ def main(argv=None):
         if env._tick != runner.steps_run:
             raise RuntimeError("bench queued %d steps, the batch counted %d" % (runner.steps_run, env._tick))
     emit()
+    # The line is out.  What follows is collective tear-down (the exchange's closing fence, a barrier, the process groups):
+    # if a rank is gone or out of step by now -- an extra leg that failed on one rank only -- it would wait for ever, and a
+    # launcher that never returns can cost the line after all.  Bounded: past the deadline every rank still here leaves, status 0
+    teardown = Watchdog(args.teardown_deadline, "tear-down after the line", status=0) if distributed else None
     if exchange is not None:
         exchange.close()                                 # collective: unmaps the peers' buffers behind a fence, ends the pump
     if distributed:
@@ -1105,6 +1112,7 @@ def main(argv=None):
             sys.stderr.flush()
             os._exit(0)
         dist.destroy_process_group()
+        teardown.cancel()
     return result
 
 

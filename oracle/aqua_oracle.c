@@ -243,7 +243,8 @@ void aqua_oracle_step(int64_t n, int K, const double* obst, int waves, double* s
                       int action_kind, const void* action, const double* noise_u, uint64_t seed, uint64_t tick,
                       int64_t env_offset, double* reward, uint8_t* term, double* margins)
 {
-#pragma omp parallel for schedule(static)
+/* (a team of threads for a handful of worlds costs a GPU box that shows 100+ cores ~0.1 s per call) */
+#pragma omp parallel for schedule(static) if (n > 1024)
     for (int64_t i = 0; i < n; ++i) {
         double s[7], u[2], m[3], vl, vr;
         for (int j = 0; j < 7; ++j) s[j] = state[j * n + i];
@@ -264,7 +265,8 @@ void aqua_oracle_step_tables(int64_t n, int K, const double* obst_all, int waves
                              int action_kind, const void* action, const double* noise_u, uint64_t seed, uint64_t tick,
                              int64_t env_offset, double* reward, uint8_t* term, double* margins)
 {
-#pragma omp parallel for schedule(static)
+/* (a team of threads for a handful of worlds costs a GPU box that shows 100+ cores ~0.1 s per call) */
+#pragma omp parallel for schedule(static) if (n > 1024)
     for (int64_t i = 0; i < n; ++i) {
         double s[7], u[2], m[3], vl, vr, mine[64 * 5];
         int Ki = 0;
