@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AQUA_HIP_LIB selects a tuning build of the same library (aquaticgymenv_amd/build.py --variants)
 LIB_PATH = os.environ.get("AQUA_HIP_LIB") or os.path.join(_HERE, "lib", "libaqua_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 ACT_U8, ACT_I32, ACT_I64, ACT_F32X2, ACT_SAMPLE_D, ACT_SAMPLE_C, ACT_BEARING = range(7)
 TERM_NONE, TERM_COLLIDED, TERM_TIME, TERM_SUCCESS = range(4)
 MAX_OBSTACLES = 64
@@ -18,7 +18,7 @@ SYMBOLS = (
     "aqua_reset_f32", "aqua_rollout_f32", "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin",
     "aqua_graph_end", "aqua_graph_launch", "aqua_graph_upload", "aqua_graph_destroy",
     "aqua_discrete_constants", "aqua_obs_norm_f32",
-    "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_step_tables_f32", "aqua_reset_tables_f32",
+    "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_tables32_floats", "aqua_step_tables_f32", "aqua_reset_tables_f32",
     "aqua_event_create", "aqua_event_record", "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
     "aqua_rollout_tables_fused_f32",
     "aqua_ipc_buffer_create", "aqua_ipc_buffer_ptr", "aqua_ipc_buffer_handle", "aqua_ipc_buffer_destroy", "aqua_ipc_open",
@@ -68,6 +68,8 @@ def _load():
     lib.aqua_ring_write_f32.argtypes = [vp, i64, i64, i64, vp, i64, ci, i64, vp]
     lib.aqua_ring_write_u8.argtypes = [vp, i64, i64, i64, vp, i64, ci, i64, vp]
     lib.aqua_pack_tables.argtypes = [vp, ci, i64, i64, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.aqua_tables32_floats.argtypes = [ci, i64]
+    lib.aqua_tables32_floats.restype = ctypes.c_size_t
     lib.aqua_step_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, vp, ci, i64, vp, i64,
                                          u64, u64, vp, vp, vp, vp, vp, ci, vp]
     lib.aqua_rollout_tables_f32.argtypes = [pp, vp, vp, ci, i64, ctypes.c_float, i64, i64, vp, i64, vp, i64, vp, ci, i64, i64,
@@ -99,7 +101,7 @@ def _load():
     for name in ("aqua_pack_obstacles", "aqua_step_f32", "aqua_reset_f32", "aqua_rollout_f32",
                  "aqua_rollout_fused_f32", "aqua_tick_advance", "aqua_graph_begin", "aqua_graph_end",
                  "aqua_graph_launch", "aqua_graph_upload", "aqua_graph_destroy",
-                 "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables",
+                 "aqua_obs_norm_f32", "aqua_ring_write_f32", "aqua_ring_write_u8", "aqua_pack_tables", "aqua_tables32_floats",
                  "aqua_step_tables_f32", "aqua_reset_tables_f32", "aqua_event_create", "aqua_event_record",
                  "aqua_event_elapsed_ms", "aqua_event_destroy", "aqua_graph_end_timed", "aqua_rollout_tables_f32",
                  "aqua_rollout_tables_fused_f32", "aqua_ipc_buffer_create", "aqua_ipc_buffer_handle", "aqua_ipc_buffer_destroy",

@@ -207,7 +207,8 @@ class BatchedAqua(object):
             self._tab32 = self._tab64 = None
             self._r_max = 0.0
             if self.per_world:
-                t32 = np.zeros((self.K, 6, self.ld), dtype=np.float32)
+                # [K][6][ld] struct of arrays + the world-major copy [ld][K][6] behind it (include/aqua_hip.h)
+                t32 = np.zeros(int(_capi.lib.aqua_tables32_floats(self.K, self.ld)), dtype=np.float32)
                 t64 = np.zeros((self.K, 5, self.ld), dtype=np.float64)
                 r_max = ctypes.c_float(0.0)
                 _capi.check(_capi.lib.aqua_pack_tables(self.obstacle_tables.ctypes.data, self.K, n, self.ld, t32.ctypes.data,

@@ -1342,12 +1342,16 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
     constexpr bool RESTART = MODE == AQUA_RESET_SAME_STEP;
     constexpr bool NS = MODE == AQUA_RESET_NEXT_STEP || MODE == TABLES_NEXT_STEP_TILE;
     constexpr bool SINK = MODE == TABLES_NEXT_STEP_TILE && KREG == 0;      // rows handed over as they are streamed (SinkShared)
-    // Same-step restart of such tables: which worlds finish is known only after the rows have gone by.  Fetching a finished
-    // world's rows again cooperatively into the same slots (REFETCH) was built and measured: 64 rows 95 -> 107-112 us per
-    // step, 32 rows 48.7 -> 49-50 (rounds of three worlds per wavefront, a barrier and a fetch each, where the groups that
-    // read their rows from memory all work at once) -- off, the code path is kept for the A/B (-DAQUA_TABLES_REFETCH)
-#ifdef AQUA_TABLES_REFETCH
-    constexpr bool REFETCH = MODE == AQUA_RESET_SAME_STEP && KREG == 0;
+    // Same-step restart of such tables: which worlds finish is known only after the rows have gone by, so the wavefront
+    // fetches a finished world's rows again into the same slots, lane j row j (REFETCH).  From the struct of arrays that
+    // was 5 K cache lines per world -- 2 M extra line requests per step at 64 rows (TCP_TCC_READ_REQ 2.69 M -> 4.66 M,
+    // profiles/r05/tables/tables_pmc64.txt), a quarter of a gigabyte, as it was for the groups that read their rows from
+    // memory (95 us per step against 61 without restarts) -- from the world-major copy behind it, 24 K contiguous bytes
+    // (-DAQUA_TABLES_NO_REFETCH: the groups read the struct of arrays, for the A/B)
+    // SINK_SPLIT == 1 (host: tables of 9 and 10 rows): the groups read the struct of arrays, two rows per round trip -- at that
+    // length the slots' rounds cost more than the scattered lines (9 rows: 15.9 us per step against 17.4)
+#ifndef AQUA_TABLES_NO_REFETCH
+    constexpr bool REFETCH = MODE == AQUA_RESET_SAME_STEP && KREG == 0 && SINK_SPLIT > 1;
 #else
     constexpr bool REFETCH = false;
 #endif
@@ -1532,9 +1536,11 @@ __device__ __forceinline__ void tables_step_block(const StepArgs& a, const float
                     if (who == 0) break;                                                    // wavefront-uniform
                     const uint32_t owner = (threadIdx.x & ~63u) + static_cast<uint32_t>(__builtin_ctzll(who));
                     if (lane < a.K) {
-                        const ObstF r = world_row(WorldTable{t32 + tile, nullptr, tld, owner}, lane);
+                        // from the world-major copy behind the struct of arrays (aqua_pack_tables): the world's K rows are
+                        // 24 K contiguous bytes -- as 5 K scattered words of the struct of arrays they were 5 K cache lines
+                        const float* const r = t32 + static_cast<int64_t>(6) * a.K * tld + ((tile + owner) * a.K + lane) * 6;
                         float* const d = &ssh.rows[wave][sl][5 * lane];
-                        d[0] = r.cx; d[1] = r.cy; d[2] = r.hx; d[3] = r.hy; d[4] = r.r2;
+                        d[0] = ld1(r); d[1] = ld1(r + 1); d[2] = ld1(r + 2); d[3] = ld1(r + 3); d[4] = ld1(r + 4);
                     }
                 }
             }
@@ -2534,6 +2540,11 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
     return e == hipSuccess ? 0 : hip_fail(e, "aqua_rollout_fused_f32 launch");
 }
 
+size_t aqua_tables32_floats(int K, int64_t tld)
+{
+    return (K < 1 || tld < 0) ? 0 : static_cast<size_t>(12) * static_cast<size_t>(K) * static_cast<size_t>(tld);
+}
+
 int aqua_pack_tables(const double* rows, int K, int64_t N, int64_t tld, float* tab32_host, double* tab64_host, float* r_max_out)
 {
     if (K < 1 || K > AQUA_MAX_OBSTACLES) return fail(AQUA_E_INVALID, "K=%d outside [1, %d]", K, AQUA_MAX_OBSTACLES);
@@ -2571,6 +2582,11 @@ int aqua_pack_tables(const double* rows, int K, int64_t N, int64_t tld, float* t
             f[4 * tld] = r2;
             f[5 * tld] = static_cast<float>(static_cast<double>(b_max) / tight(std::sqrt(static_cast<double>(r2))));
         }
+    // the world-major copy behind the struct of arrays: [tld][K][6], a world's table contiguous (tables_world_major())
+    float* const aos = tab32_host + static_cast<size_t>(6) * K * tld;
+    for (int64_t i = 0; i < N; ++i)
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < 6; ++c) aos[(i * K + k) * 6 + c] = tab32_host[(6 * k + c) * tld + i];
     *r_max_out = static_cast<float>(r_max);
     return 0;
 }
@@ -2638,7 +2654,8 @@ hipError_t launch_step_tables(const StepArgs& a0, const TableArgs& t, int kind, 
         else if (interleave) hipLaunchKernelGGL((step_tables_ns_kernel<AK, true>), AQUA_TAB_ARGS);                           \
         else if (ns) hipLaunchKernelGGL((step_tables_ns_kernel<AK, false>), AQUA_TAB_ARGS);                                  \
         else if (a.auto_reset && a.K >= SINK_SPLIT_LONG_MIN_ROWS) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0, SINK_SPLIT_LONG>), AQUA_TAB_ARGS); \
-        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0>), AQUA_TAB_ARGS);         \
+        else if (a.auto_reset && a.K > TABLES_KREG_WIDE) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0>), AQUA_TAB_ARGS); \
+        else if (a.auto_reset) hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_SAME_STEP, 0, 1>), AQUA_TAB_ARGS);      \
         else hipLaunchKernelGGL((step_tables_kernel<AK, AQUA_RESET_NONE, 0>), AQUA_TAB_ARGS);                                \
         break;
     switch (kind) {

@@ -35,12 +35,14 @@
 extern "C" {
 #endif
 
-#define AQUA_ABI_VERSION 7   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
+#define AQUA_ABI_VERSION 8   /* 2: the obstacle blob of tables of up to 8 rows ends with the quick table;
                                 3: aqua_rollout_f32 takes advance_tick, timing events, aqua_graph_end_timed;
                                 4: aqua_rollout_tables_fused_f32;
                                 5: aqua_ipc_*, aqua_copy_async (done-mask exchange by peer copies);
                                 6: aqua_rollout_events_f32 (events attached to the first / last launch);
-                                7: aqua_graph_upload */
+                                7: aqua_graph_upload;
+                                8: tab32 of the per-world tables carries a world-major copy behind the struct of arrays
+                                   (aqua_tables32_floats) */
 
 /* library error codes (negative) */
 #define AQUA_E_INVALID   (-1)   /* bad argument (null pointer, negative size, K too large ...) */
@@ -194,7 +196,10 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
  * aqua_pack_tables() converts rows[N][K][5] float64 (the reference's format, cx, cy, kind 0 circle | 1 rectangle,
  * a, b; kind < 0 marks an absent row, so worlds may hold fewer than K obstacles) into the two device-format arrays,
  * on the HOST; the caller uploads them:
- *   tab32  float32 [K][6][tld]  (cx, cy, hx, hy, R^2, w) per row, struct of arrays over the worlds (coalesced)
+ *   tab32  float32 [K][6][tld]  (cx, cy, hx, hy, R^2, w) per row, struct of arrays over the worlds (coalesced: what the
+ *          step streams), FOLLOWED BY the same rows world-major, float32 [tld][K][6]: a world's whole table contiguous --
+ *          what a restart re-reads (one world's K rows are 6 K different cache lines of the struct of arrays, 1.5 K / 128
+ *          of the copy).  aqua_tables32_floats(K, tld) = 12 K tld is the size of the buffer in floats.
  *   tab64  float64 [K][5][tld]  the rows as given, for the float64 knife-edge path
  * and returns the largest collision radius of the batch in *r_max (sizes the knife-edge bands).
  *
@@ -205,6 +210,7 @@ int aqua_rollout_fused_f32(const AquaParams* p, const void* obst_blob_dev, int K
  * worlds all hold the same list are bit-identical to the shared-table calls.  Algorithmic bytes per world-step:
  * 62 + 24 K (discrete).
  */
+size_t aqua_tables32_floats(int K, int64_t tld);
 int aqua_pack_tables(const double* rows, int K, int64_t N, int64_t tld, float* tab32_host, double* tab64_host,
                      float* r_max);
 int aqua_step_tables_f32(const AquaParams* p, const float* tab32_dev, const double* tab64_dev, int K, int64_t tld,

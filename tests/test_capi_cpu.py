@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(capi):
     raw = ctypes.CDLL(capi.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert capi.lib.aqua_version() == capi.ABI_VERSION == 7
+    assert capi.lib.aqua_version() == capi.ABI_VERSION == 8
     assert ctypes.sizeof(capi.AquaParams) == 32
 
 
@@ -124,11 +124,15 @@ def test_pack_tables_layout(capi):
     rows[:, 1] = [60, 70, 1, 8, 6]            # rectangle 8 x 6   -> R = 2.5
     rows[:, 2] = [0, 0, -1, 0, 0]             # absent
     rows[3, 0, 3] = 4.0                       # world 3: smaller circle
-    t32 = np.zeros((K, 6, tld), dtype=np.float32)
+    assert lib.aqua_tables32_floats(K, tld) == 12 * K * tld and lib.aqua_tables32_floats(0, tld) == 0
+    buf = np.zeros(lib.aqua_tables32_floats(K, tld), dtype=np.float32)
+    t32 = buf[: K * 6 * tld].reshape(K, 6, tld)                 # struct of arrays over the worlds ...
+    aos = buf[K * 6 * tld:].reshape(tld, K, 6)                  # ... and the same rows world-major behind it
     t64 = np.zeros((K, 5, tld), dtype=np.float64)
     r_max = ctypes.c_float(0)
-    assert lib.aqua_pack_tables(rows.ctypes.data, K, n, tld, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == 0
+    assert lib.aqua_pack_tables(rows.ctypes.data, K, n, tld, buf.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == 0
     assert r_max.value == 12.5
+    assert np.array_equal(aos[:n], t32[:, :, :n].transpose(2, 0, 1)) and np.all(aos[n:] == 0)
     assert np.array_equal(t64[:, :, :n], rows.transpose(1, 2, 0))
     assert np.all(t32[0, 4, :n] == np.float32([156.25, 156.25, 156.25, 42.25, 156.25]))
     assert np.all(t32[1, 2, :n] == 4.0) and np.all(t32[1, 3, :n] == 3.0) and np.all(t32[1, 4, :n] == 6.25)
@@ -136,8 +140,8 @@ def test_pack_tables_layout(capi):
     assert np.all(t32[0, 5, [0, 1, 2, 4]] == 1.0) and t32[0, 5, 3] > 1.0     # band scale 1 at R_max, > 1 below it
     assert np.all(t32[1, 5, :n] > 5.0)
     bad = rows.copy(); bad[0, 0, 2] = 2.0
-    assert lib.aqua_pack_tables(bad.ctypes.data, K, n, tld, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == -1
-    assert lib.aqua_pack_tables(rows.ctypes.data, K, n, 4, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == -1
+    assert lib.aqua_pack_tables(bad.ctypes.data, K, n, tld, buf.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == -1
+    assert lib.aqua_pack_tables(rows.ctypes.data, K, n, 4, buf.ctypes.data, t64.ctypes.data, ctypes.byref(r_max)) == -1
 
 
 def test_ring_write_validation_without_touching_a_device(capi):

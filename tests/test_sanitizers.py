@@ -81,9 +81,9 @@ def test_host_half_of_the_product_library_under_sanitizers():
     p = _child([sys.executable, "-m", "pytest", os.path.join("tests", "test_capi_cpu.py"), "-x", "-q", "-p", "no:cacheprovider"],
                runtime, {"AQUA_HIP_LIB": lib})
     assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-2000:]
-    # control: a per-world table buffer one row short is reported as a heap overflow inside aqua_pack_tables
+    # control: a per-world table buffer one row of the world-major copy short is reported as a heap overflow inside aqua_pack_tables
     code = ("import sys; sys.path.insert(0, %r)\nimport ctypes, numpy as np\nfrom aquaticgymenv_amd import _capi\n"
-            "n, k, ld = 100, 4, 128\nrows = np.zeros((n, k, 5)); rows[:, :, 3] = 1.0\n"
-            "t32 = np.zeros((k - 1, 6, ld), dtype=np.float32); t64 = np.zeros((k, 5, ld)); r = ctypes.c_float(0)\n"
+            "n, k, ld = 128, 4, 128\nrows = np.zeros((n, k, 5)); rows[:, :, 3] = 1.0\n"
+            "t32 = np.zeros(12 * k * ld - 6, dtype=np.float32); t64 = np.zeros((k, 5, ld)); r = ctypes.c_float(0)\n"
             "_capi.lib.aqua_pack_tables(rows.ctypes.data, k, n, ld, t32.ctypes.data, t64.ctypes.data, ctypes.byref(r))\n" % ROOT)
     _child([sys.executable, "-c", code], runtime, {"AQUA_HIP_LIB": lib}, expect_report="heap-buffer-overflow")
