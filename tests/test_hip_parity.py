@@ -1645,3 +1645,42 @@ def test_clipped_action_counter(torch):
     other.load_state_dict(ckpt)
     assert int(other.clipped_actions) == 14
     assert _make(torch, n, presets.NONE, continuous=True).clipped_actions is None
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["no_restart", "same_step", "next_step"])
+def test_captured_step_equals_step(torch, mode):
+    """BatchedAqua.capture_step: ONE step as a HIP graph that re-reads the caller's action buffer at every replay (a policy
+    writes into it in between) == step() with the same actions, bit for bit -- shared table and per-world tables of 8 and 20
+    rows, discrete and continuous, Philox noise (the graph advances the device's tick base), the clipped-action counter;
+    a buffer the graph could not re-read is refused."""
+    from aquaticgymenv_amd import presets
+    n, T = 3000 + 5, 12
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rng = np.random.RandomState(6)
+    for obstacles, continuous in ((presets.BENCH8, False), (presets.BENCH8, True), (_random_tables(rng, n, 8), False), (_random_tables(rng, n, 20), False)):
+        a = _make(torch, n, obstacles, continuous=continuous, seed=12, auto_reset=mode, count_clipped=continuous)
+        b = _make(torch, n, obstacles, continuous=continuous, seed=12, auto_reset=mode, count_clipped=continuous)
+        a.reset(); b.reset()
+        if continuous:
+            seq = torch.rand((T, 2, a.ld), device="cuda", generator=g) * 0.34 + 0.18          # some thrusts outside [0.2, 0.5]
+            buf = torch.zeros((2, a.ld), dtype=torch.float32, device="cuda")
+        else:
+            seq = torch.randint(0, 3, (T, n), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+            buf = torch.zeros(n, dtype=torch.int32, device="cuda")
+        graph = b.capture_step(buf, soa=continuous)
+        for t in range(T):
+            _, r1, c1 = a.step(seq[t], soa=continuous)
+            buf.copy_(seq[t])
+            r2, c2 = graph.launch()
+            assert torch.equal(r1, r2[:n]) and torch.equal(c1, c2[:n]), "step %d differs" % t
+        assert torch.equal(a.state, b.state) and torch.equal(a.time, b.time) and a._tick == b._tick == T
+        if continuous:
+            assert int(a.clipped_actions) == int(b.clipped_actions) > 0
+    env = _make(torch, n, presets.BENCH8, seed=1)
+    with pytest.raises(ValueError):
+        env.capture_step(torch.zeros(n, dtype=torch.int32))                     # a host tensor
+    with pytest.raises(ValueError):
+        env.capture_step(torch.zeros(2 * n, dtype=torch.int32, device="cuda")[::2])       # not contiguous: step() would copy it
+    cont = _make(torch, n, presets.BENCH8, continuous=True, seed=1)
+    with pytest.raises(ValueError):
+        cont.capture_step(torch.zeros((n, 2), device="cuda"))                   # [N][2] is staged by step(): soa only
