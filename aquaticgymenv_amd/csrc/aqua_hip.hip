@@ -1160,12 +1160,18 @@ __global__ __launch_bounds__(rollout_threads(MODE), rollout_threads(MODE) / 64) 
         __syncthreads();
     }
     constexpr int QUICK = SMALL ? QUICK_ALWAYS : QUICK_NEVER;
-    const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
     const uint64_t tick0 = launch_tick(a);
     const int64_t N = a.N, ld = a.ld;
     uint32_t q0 = 0;                                       // posts of this block's earlier tiles (the mailbox's sequence)
     if constexpr (MAIL) {
         if (threadIdx.x >= BLOCK_SMALL) {                  // the re-seeding wavefront follows the others through the same tiles
+            // its own constants, made on its side of the split: the stepping wavefronts keep the quick table's first groups
+            // in 32 SGPRs for the whole rollout, this wavefront reads the groups as it goes -- made ahead of the split, the
+            // two paths' scalar registers added up, and how many of them the compiler then spilled inside the step loop
+            // depended on what ELSE was in the translation unit (the library 119 lane moves per step against 72 for the
+            // same source built with one action kind: 4.08 against 3.60 us per step, profiles/r05/fused_mail/fused_time_d.txt)
+            StepConst k = make_const<QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
+            if constexpr (SMALL) k.quick = (QuickPtr)(uintptr_t)(reinterpret_cast<const char*>(a.obst_blob) + quick_offset(a.K));
             if (AQUA_MAIL_PRIO) __builtin_amdgcn_s_setprio(AQUA_MAIL_PRIO);
             for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
                  bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL, q0 += static_cast<uint32_t>(a.T))
@@ -1174,6 +1180,16 @@ __global__ __launch_bounds__(rollout_threads(MODE), rollout_threads(MODE) / 64) 
             return;
         }
     }
+#ifdef AQUA_FUSED_QUICK_RESIDENT              // (A/B: the quick table's first groups held in SGPRs for the whole rollout)
+    const StepConst k = make_const<SMALL ? QUICK_IF_PRESENT : QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
+#else
+    // The quick table's first two groups are NOT kept in scalar registers across the steps (they are in the one-launch-per-
+    // step kernels, where they are loaded once and used once): 32 SGPRs held through a loop whose body needs ~100 were
+    // spilled to VGPR lanes and read back lane by lane in front of every obstacle test -- how many, the compiler decided
+    // differently from build to build of the same source.  Each step re-reads the groups from the scalar cache instead.
+    StepConst k = make_const<QUICK_NEVER>(a, obstacle_rows(a.obst_blob));
+    if constexpr (SMALL) k.quick = (QuickPtr)(uintptr_t)(reinterpret_cast<const char*>(a.obst_blob) + quick_offset(a.K));
+#endif
     // whole blocks iterate together; lanes past N are inert
     for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * BLOCK_SMALL; bbase < N;
          bbase += static_cast<int64_t>(gridDim.x) * BLOCK_SMALL, q0 += static_cast<uint32_t>(a.T)) {
@@ -1204,6 +1220,8 @@ __global__ __launch_bounds__(rollout_threads(MODE), rollout_threads(MODE) / 64) 
                     serve_reseed<SMALL>(tk, a, k, tick, bbase, sh, parity);     // one wavefront; the others go on stepping
                 }
             }
+            // (the next step's action fetched one step ahead was measured: next-step 3.61 = 3.64, no restart 1.39 -> 1.51 us per
+            // step, profiles/r05/fused_mail/fused_time_d.txt: not used)
             int idx = 2;
             float vl = 0.5f, vr = 0.5f;
             if constexpr (AK == AQUA_ACT_U8) idx = fold_index(static_cast<const uint8_t*>(a.action)[s * a.action_step_stride + ic]);
@@ -1231,8 +1249,16 @@ __global__ __launch_bounds__(rollout_threads(MODE), rollout_threads(MODE) / 64) 
             EnvState after = e;
             float rew;
             uint32_t code;
+#ifndef AQUA_FUSED_QUICK_RESIDENT
+            if constexpr (SMALL) {
+                QuickPtr q = k.quick;
+                asm volatile("" : "+s"(q));                 // (laundered: the loads stay inside the step)
+                k.qc0 = quick_circles(q, QUICK_C0);
+                k.qr0 = quick_rects(q, QUICK_R0);
+            }
+#endif
             const bool knife = fast_step<false, QUICK>(after, m.h, m.w, m.chord, u0, u1, k, rew, code) && valid && !pending;
-            if (any_lane(knife)) {
+            if (__builtin_expect(any_lane(knife), 0)) {
                 if (knife) {
                     const ExactOut o = exact_step(before.x, before.y, before.th, before.gx, before.gy, before.wx,
                                                   before.wy, after.t, exact_motion<AK>(m), k.K, k.obst64, k.obst, k.band2,
