@@ -1231,11 +1231,20 @@ __global__ __launch_bounds__(rollout_threads(MODE), rollout_threads(MODE) / 64) 
                 const float* base = static_cast<const float*>(a.action) + s * a.action_step_stride;
                 vl = base[ic]; vr = base[a.action_ld + ic];
             }
+            // (Philox's ten round keys are loop invariants: the compiler hoists them out of the step loop, holds twenty more
+            // scalar registers through it, spills them to VGPR lanes and reads them back with a v_readlane + s_nop in front of
+            // every round.  Laundering the seed per step -- the keys re-made by scalar additions, 25 % fewer lane moves in the
+            // loop -- was measured with all action kinds built: no restart 1.27 -> 1.32 us per step, same-step 3.79 -> 3.88,
+            // next-step 3.87 = 3.87; per-world fused no restart 1.57 -> 1.75.  Lane moves are not the cost; not used.)
+            uint64_t seed = a.seed;
+#ifdef AQUA_FUSED_KEYS_LAUNDERED              // (A/B timing)
+            asm volatile("" : "+s"(seed));
+#endif
             uint32_t w0[1], w1[1];
-            pair_draws<1, false>(a.seed, env, tick, STREAM_STEP, w0, w1);
+            pair_draws<1, false>(seed, env, tick, STREAM_STEP, w0, w1);
             const float u0 = u_pm1(w0[0]), u1 = u_pm1(w1[0]);
             if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
-                pair_draws<1, false>(a.seed, env, tick, STREAM_ACT, w0, w1);
+                pair_draws<1, false>(seed, env, tick, STREAM_ACT, w0, w1);
                 if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(w0[0]);
                 else { vl = sample_thrust(w0[0]); vr = sample_thrust(w1[0]); }
             }
@@ -1862,11 +1871,12 @@ __device__ __forceinline__ void rollout_tables_body(const StepArgs& a, const flo
                 const float* base = static_cast<const float*>(a.action) + s * a.action_step_stride;
                 vl = base[ic]; vr = base[a.action_ld + ic];
             }
+            const uint64_t seed = a.seed;
             uint32_t w0[1], w1[1];
-            pair_draws<1, false>(a.seed, env, tick, STREAM_STEP, w0, w1);
+            pair_draws<1, false>(seed, env, tick, STREAM_STEP, w0, w1);
             const float u0 = u_pm1(w0[0]), u1 = u_pm1(w1[0]);
             if constexpr (AK >= AQUA_ACT_SAMPLE_D) {
-                pair_draws<1, false>(a.seed, env, tick, STREAM_ACT, w0, w1);
+                pair_draws<1, false>(seed, env, tick, STREAM_ACT, w0, w1);
                 if constexpr (AK == AQUA_ACT_SAMPLE_D) idx = sample_discrete(w0[0]);
                 else { vl = sample_thrust(w0[0]); vr = sample_thrust(w1[0]); }
             }
