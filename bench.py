@@ -1162,7 +1162,7 @@ def kernel_only(n, args, a_bytes):
     except Exception:
         return {"avg_ns": None, "frac": None, "source": "no profiles/traffic.json"}
     key = "n%d_%s_%s" % (n, "cont" if args.continuous else "disc", "k0" if args.no_obstacles else "k8")
-    row = table.get(key)
+    row = table.get("%s_steps%d" % (key, args.steps)) or table.get(key)          # (a trace of this very command, if there is one)
     if not row or "step_kernel_avg_ns" not in row:
         return {"avg_ns": None, "frac": None, "source": "no committed kernel trace for " + key}
     tag = library_tag()

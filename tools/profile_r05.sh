@@ -12,6 +12,6 @@ bash tools/profile_round.sh $T/n16m --envs 16777216 --steps 100 --warmup 20 || e
 bash tools/profile_round.sh $T/n262144_cont --continuous --steps 500 --warmup 100 || exit 1
 bash tools/pmc_sq.sh $T/pmc_sq > $R/gpurun_out/$T/pmc_sq.txt 2>&1
 O=$R/gpurun_out/$T
-python3 tools/make_traffic.py $O n262144_disc_k8=n262144 n16777216_disc_k8=n16m n262144_cont_k8=n262144_cont > $O/traffic.log 2>&1 || { cat $O/traffic.log; exit 1; }
+python3 tools/make_traffic.py $O n262144_disc_k8=n262144 n262144_disc_k8_steps20=k20 n16777216_disc_k8=n16m n262144_cont_k8=n262144_cont > $O/traffic.log 2>&1 || { cat $O/traffic.log; exit 1; }
 cp profiles/traffic.json $O/traffic.json
 tail -5 $O/pmc_sq.txt
