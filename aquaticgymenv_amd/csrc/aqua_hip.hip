@@ -2127,6 +2127,8 @@ thread_local char g_err[512] = "";
 // kernel is being worked on; the other kinds then fail with hipErrorInvalidValue.
 #ifdef AQUA_DEV_U8_ONLY
 #define AQUA_DEV_OTHER_KINDS(LAUNCH)
+#elif defined(AQUA_DEV_TWO_KINDS)
+#define AQUA_DEV_OTHER_KINDS(LAUNCH) LAUNCH(AQUA_ACT_SAMPLE_D)
 #else
 #define AQUA_DEV_OTHER_KINDS(LAUNCH)                                                                       \
     LAUNCH(AQUA_ACT_I32) LAUNCH(AQUA_ACT_I64) LAUNCH(AQUA_ACT_F32X2) LAUNCH(AQUA_ACT_SAMPLE_D) LAUNCH(AQUA_ACT_SAMPLE_C) \
