@@ -34,6 +34,10 @@ def load_traj():
     return np.load(os.path.join(GOLDEN, "traj_golden.npz"))
 
 
+def load_episodes():
+    return np.load(os.path.join(GOLDEN, "episodes_golden.npz"))
+
+
 def load_reset():
     return np.load(os.path.join(GOLDEN, "reset_golden.npz"))
 

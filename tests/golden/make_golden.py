@@ -472,6 +472,67 @@ def gen_policy_stats(mod):
     return out
 
 
+def gen_episodes(mod):
+    """Whole episodes of the reference, back to back, as the loop of main/testing/__init__.py:17-36 produces them: reset(),
+    then get_action -> step until done, reset() again.  The policy is the bearing rule with one action in ten replaced by a
+    random one (so that episodes end at the goal, on obstacles and on the border); continuous configurations get the rule's
+    thrust pair with a seeded jitter.  Recorded per step and world: the action, the two wave draws (replayed from the seed
+    of numpy's global generator, which step() alone consumes), the reference's state / reward / code after the step, and --
+    where the episode ended -- the state its reset() produced, which a replay has to be GIVEN (reset parity is
+    distributional).  Own random streams: nothing of the older fixtures moves."""
+    out = {}
+    T, W = 400, 6
+    cfgs = (0, 1, 3, 4)
+    thrust = {0: (0.2, 0.5), 1: (0.5, 0.2), 2: (0.5, 0.5)}
+    for ci in cfgs:
+        cfg = CONFIGS[ci]
+        continuous = cfg[2]
+        st0 = np.zeros((W, 7))
+        after = np.zeros((T, W, 7))
+        fresh = np.zeros((T, W, 7))
+        act_i = np.zeros((T, W), dtype=np.int32)
+        act_c = np.zeros((T, W, 2))
+        noise = np.zeros((T, W, 2))
+        rew = np.zeros((T, W))
+        term = np.zeros((T, W), dtype=np.int32)
+        ends = 0
+        for w in range(W):
+            env = make_env(mod, cfg)
+            pol = np.random.RandomState(9100 + 10 * ci + w)
+            for _ in range(5 * w):                   # (every env object's sampler starts from the same seed: world w skips ahead)
+                env.reset()
+            obs = env.reset()
+            st0[w] = np.concatenate([env._boat_state, env._goal_state, env._wave_speed])
+            sigma = env.wave_speed_variance
+            seed = 31000 + 10 * ci + w
+            np.random.seed(seed)
+            replay = np.random.RandomState(seed)
+            for t in range(T):
+                a = bearing_action(obs) if pol.uniform() >= 0.1 else int(pol.randint(3))
+                ac = f32r(np.clip(np.asarray(thrust[a]) + pol.uniform(-0.02, 0.02, 2), 0.2, 0.5))
+                wave_before = env._wave_speed.copy()
+                d = replay.uniform(-sigma, sigma, 2)
+                obs, r, done, info = env.step(np.array(ac, dtype=np.float32) if continuous else a)
+                assert np.array_equal(env._wave_speed, np.clip(wave_before + d, env.wave_min_speed, env.wave_max_speed)), \
+                    "the replayed draws are not the ones step() consumed"
+                code = 1 if info["Termination.collided"] else 2 if info["Termination.time"] else \
+                    3 if info["Termination.success"] else 0
+                act_i[t, w], act_c[t, w], noise[t, w] = a, ac, d / sigma
+                after[t, w] = np.concatenate([obs, env._wave_speed])
+                rew[t, w], term[t, w] = float(r), code
+                if done:
+                    obs = env.reset()
+                    fresh[t, w] = np.concatenate([env._boat_state, env._goal_state, env._wave_speed])
+                    ends += 1
+        for name, arr in (("state0", st0), ("after", after), ("fresh", fresh), ("action_i", act_i), ("action_c", act_c),
+                          ("noise_u", noise), ("reward", rew), ("term", term)):
+            out["ep_cfg%d_%s" % (ci, name)] = arr
+        print("episodes, %s: %d worlds x %d steps, %d episodes ended (%s)" % (
+            cfg[0], W, T, ends, np.bincount(term.reshape(-1), minlength=4).tolist()))
+    out["ep_cfgs"] = np.asarray(cfgs, dtype=np.int32)
+    return out
+
+
 def gen_dqn_fixture():
     """weights of the reference's two trained DQN policies (example_policies/*/models/model-000NN, Keras
     SavedModel variables read with aquaticgymenv_amd.tf_import -- TensorFlow is not installable here) and the
@@ -539,6 +600,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "reset_golden.npz"), **gen_resets(mod))
     np.savez_compressed(os.path.join(HERE, "policy_golden.npz"), **gen_policy_stats(mod))
     np.savez_compressed(os.path.join(HERE, "dqn_policies.npz"), **gen_dqn_fixture())
+    np.savez_compressed(os.path.join(HERE, "episodes_golden.npz"), **gen_episodes(mod))
     terms = np.bincount(cols["term"], minlength=4)
     print("rows", len(rows), "hand", n_hand, "term histogram", terms.tolist())
     band = (np.abs(cols["m_border"]) < 1e-4) | (np.abs(cols["m_obst"]) < 1e-4) | (np.abs(cols["m_goal"]) < 1e-4)

@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from tests._golden import StepGolden, load_traj, angle_diff
+from tests._golden import StepGolden, load_traj, load_episodes, angle_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -155,6 +155,94 @@ def test_step_and_replayed_graph_walk_the_same_trajectory(torch):
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("mode", ["step", "graph"])
+@pytest.mark.parametrize("ci", [0, 1, 3, 4])
+def test_whole_episodes_of_the_reference(torch, oracle, ci, mode):
+    """tests/golden/episodes_golden.npz: the reference's own evaluation loop (main/testing/__init__.py:17-36: reset, act, step
+    until done, reset again) over 400 steps and six worlds, bearing policy with one random action in ten -- episodes of
+    60-150 steps that end AT THE GOAL, on obstacles and on the border (the five trajectories above all end within 13 steps and
+    drift on outside the world).  The kernel's float32 state is its own inside every episode; where the reference's episode
+    ended, the worlds are given the state the reference's reset() produced (reset parity is distributional).  Same bars:
+    pose / theta / step reward within TOL_TRAJ at every step, wave within TOL_WAVE, every termination code equal unless the
+    reference's own margin at that step is inside BAND."""
+    from aquaticgymenv_amd.batched import BatchedAqua
+    z, g = load_episodes(), StepGolden()
+    cfg = g.cfg(ci)
+    after, fresh, term_ref, rew_ref = (z["ep_cfg%d_%s" % (ci, k)] for k in ("after", "fresh", "term", "reward"))
+    T, W = term_ref.shape
+    # the reference's margins at every step, one oracle call: world (t, w) steps from the state the reference stepped from
+    before = np.empty_like(after)
+    before[0] = z["ep_cfg%d_state0" % ci]
+    ended = term_ref != 0
+    before[1:] = np.where(ended[:-1, :, None], fresh[:-1], after[:-1])
+    tin = np.zeros((T, W), dtype=np.int32)
+    for t in range(1, T):
+        tin[t] = np.where(ended[t - 1], 0, tin[t - 1] + 1)
+    s = np.ascontiguousarray(before.reshape(T * W, 7).T.astype(np.float64))
+    if cfg["continuous"]:
+        a_all = np.ascontiguousarray(z["ep_cfg%d_action_c" % ci].reshape(T * W, 2).T.astype(np.float32))
+    else:
+        a_all = z["ep_cfg%d_action_i" % ci].reshape(T * W).astype(np.int64)
+    _, term_o, m = oracle.step(s, np.ascontiguousarray(tin.reshape(-1)), a_all, obstacles=cfg["obstacles"], waves=cfg["waves"],
+                               noise_u=np.ascontiguousarray(z["ep_cfg%d_noise_u" % ci].reshape(T * W, 2).T))
+    assert np.array_equal(term_o.reshape(T, W), term_ref)
+    near = (np.min(np.abs(m), axis=0) <= BAND).reshape(T, W)
+
+    env = BatchedAqua(W, obstacles=cfg["obstacles"], waves=bool(cfg["waves"]), continuous=cfg["continuous"], seed=5,
+                      auto_reset=False, device="cuda:0")
+    env.set_state(z["ep_cfg%d_state0" % ci].astype(np.float32), np.zeros(W, dtype=np.int32))
+    ld = env.ld
+    pad = lambda x: torch.nn.functional.pad(x, (0, ld - W))                       # noqa: E731
+    noise_seq = pad(torch.as_tensor(z["ep_cfg%d_noise_u" % ci].astype(np.float32)).permute(0, 2, 1).contiguous()).cuda()      # [T][2][ld]
+    if cfg["continuous"]:
+        act_seq = pad(torch.as_tensor(z["ep_cfg%d_action_c" % ci].astype(np.float32)).permute(0, 2, 1).contiguous()).cuda()
+        action = torch.zeros((2, ld), dtype=torch.float32, device="cuda:0")
+    else:
+        act_seq = torch.as_tensor(z["ep_cfg%d_action_i" % ci].astype(np.int64)).cuda()
+        action = torch.zeros(W, dtype=torch.int64, device="cuda:0")
+    fresh_dev = torch.as_tensor(fresh.astype(np.float32)).permute(0, 2, 1).contiguous().cuda()          # [T][7][W]
+    ended_dev = torch.as_tensor(ended).cuda()
+    noise = torch.zeros((2, ld), dtype=torch.float32, device="cuda:0")
+    graph = env.capture_step(action, noise=noise, soa=cfg["continuous"]) if mode == "graph" else None
+    states = torch.zeros((T, 7, W), dtype=torch.float32, device="cuda:0")
+    rews = torch.zeros((T, W), dtype=torch.float32, device="cuda:0")
+    terms = torch.zeros((T, W), dtype=torch.uint8, device="cuda:0")
+    for t in range(T):
+        noise.copy_(noise_seq[t])
+        action.copy_(act_seq[t])
+        if graph is not None:
+            r, c = graph.launch()
+        else:
+            _, r, c = env.step(action, soa=cfg["continuous"], noise=noise)
+        states[t].copy_(env.state[:, :W])
+        rews[t].copy_(r[:W])
+        terms[t].copy_(c[:W])
+        # where the REFERENCE's episode ended, its reset() state and time 0 (the kernel's code is compared below)
+        env.state[:, :W] = torch.where(ended_dev[t], fresh_dev[t], env.state[:, :W])
+        env.time[:W] = torch.where(ended_dev[t], torch.zeros_like(env.time[:W]), env.time[:W])
+    torch.cuda.synchronize()
+    got = states.permute(0, 2, 1).cpu().numpy().astype(np.float64)               # [T][W][7]
+    rew, term = rews.cpu().numpy().astype(np.float64), terms.cpu().numpy()
+    differ = term != term_ref
+    assert not (differ & ~near).any(), "termination codes differ away from every threshold: %s" % (np.argwhere(differ & ~near)[:5],)
+    d_pose = np.maximum(np.abs(got[..., 0] - after[..., 0]), np.abs(got[..., 1] - after[..., 1]))
+    d_theta = angle_diff(got[..., 2], after[..., 2])
+    d_wave = np.max(np.abs(got[..., 5:7] - after[..., 5:7]), axis=2)
+    d_rew = np.abs(rew - rew_ref)[~differ]
+    key = "episodes_cfg%d_%s" % (ci, mode)
+    OBSERVED[key] = {"config": cfg["name"], "max_pose": float(d_pose.max()), "max_theta": float(d_theta.max()),
+                     "max_wave": float(d_wave.max()), "max_reward": float(d_rew.max()),
+                     "episodes": {"collided": int((term_ref == 1).sum()), "time": int((term_ref == 2).sum()), "success": int((term_ref == 3).sum())},
+                     "longest_episode_steps": int(tin.max()) + 1, "codes_differing_inside_band": int(differ.sum()),
+                     "steps_with_reference_inside_band": int(near.sum())}
+    print("\n%s (%s): %d episodes; max |d pose| %.2e  |d theta| %.2e  |d wave| %.2e  |d reward| %.2e; %d codes inside the band differ"
+          % (key, cfg["name"], int(ended.sum()), d_pose.max(), d_theta.max(), d_wave.max(), d_rew.max(), int(differ.sum())))
+    assert d_pose.max() <= TOL_TRAJ and d_theta.max() <= TOL_TRAJ and d_wave.max() <= TOL_WAVE and d_rew.max() <= TOL_TRAJ
+    both_ended = ~differ & ended
+    assert np.array_equal(rew[both_ended], rew_ref[both_ended])                  # terminal rewards are exact
+    assert int((term_ref == 3).sum()) >= 10 and int((term_ref == 1).sum()) >= 2
+
+
 def test_zz_write_observed_drift():
     """(last in the file) the figures DESIGN.md section 3 quotes"""
     if not OBSERVED:
@@ -162,7 +250,7 @@ def test_zz_write_observed_drift():
     worst = {k: max(v[k] for v in OBSERVED.values()) for k in ("max_pose", "max_theta", "max_wave", "max_reward")}
     out = {"T": T_STEPS, "tolerance": {"pose_theta_reward": TOL_TRAJ, "wave": TOL_WAVE, "band": BAND}, "worst": worst,
            "cases": OBSERVED}
-    print("\nfree-running drift over %d steps, worst of %d cases: %s" % (T_STEPS, len(OBSERVED), worst))
+    print("\nfree-running drift, worst of %d cases (260-step trajectories and 400-step episode sequences): %s" % (len(OBSERVED), worst))
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(root):
         with open(os.path.join(root, "free_running.json"), "w") as f:

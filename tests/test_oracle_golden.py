@@ -11,7 +11,7 @@ threshold is below 1e-4.
 import numpy as np
 import pytest
 
-from tests._golden import StepGolden, load_traj, angle_diff
+from tests._golden import load_episodes, StepGolden, load_traj, angle_diff
 from oracle.aqua_oracle import ScalarPort
 
 
@@ -246,3 +246,33 @@ def test_every_entry_point_of_the_c_oracle_at_ragged_sizes(oracle, n):
     st, tt = before.copy(), np.zeros(n, dtype=np.int32)
     oracle.rollout_f32(st, tt, 1, obstacles=rows, actions=acts, seed=5, tick0=1, env_offset=3, auto_reset=1)
     assert oracle.threads() >= 1
+
+
+def test_c_oracle_reproduces_the_references_whole_episodes(oracle):
+    """tests/golden/episodes_golden.npz: the reference's own loop (reset, act, step until done, reset again) over 400 steps
+    and six worlds per configuration, bearing policy with one random action in ten -- episodes that end at the goal, on
+    obstacles and on the border.  The float64 oracle, free-running inside an episode and given the reference's reset states
+    at the boundaries, reproduces every state, reward and code."""
+    z = load_episodes()
+    g = StepGolden()
+    for ci in [int(c) for c in z["ep_cfgs"]]:
+        cfg = g.cfg(ci)
+        after, fresh, term_ref, rew_ref = (z["ep_cfg%d_%s" % (ci, k)] for k in ("after", "fresh", "term", "reward"))
+        T, W = term_ref.shape
+        state = np.ascontiguousarray(z["ep_cfg%d_state0" % ci].T.astype(np.float64))
+        time = np.zeros(W, dtype=np.int32)
+        for t in range(T):
+            if cfg["continuous"]:
+                a = np.ascontiguousarray(z["ep_cfg%d_action_c" % ci][t].T.astype(np.float32))
+            else:
+                a = z["ep_cfg%d_action_i" % ci][t].astype(np.int64)
+            rew, term, _ = oracle.step(state, time, a, obstacles=cfg["obstacles"], waves=cfg["waves"],
+                                       noise_u=np.ascontiguousarray(z["ep_cfg%d_noise_u" % ci][t].T))
+            assert np.array_equal(term, term_ref[t]), (ci, t)
+            assert np.max(np.abs(rew - rew_ref[t])) < 1e-6
+            assert np.max(np.abs(state[[0, 1, 5, 6]] - after[t].T[[0, 1, 5, 6]])) < 1e-6
+            assert np.max(angle_diff(state[2], after[t][:, 2])) < 1e-9
+            done = term != 0
+            state[:, done] = fresh[t][done].T                       # the reference's own reset() states
+            time[done] = 0
+        assert int((term_ref != 0).sum()) >= 15 and {1, 3} <= set(np.unique(term_ref))
