@@ -864,12 +864,12 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
     }
 }
 
-// The next-step fused rollout's hand-over (round 5): NO barrier, a wavefront of its own that only re-seeds, and TWO steps of
-// slack for it.  A world that finishes at step s is not needed again before step s + 2 (during step s + 1 it does not
-// move: that tick reports reward 0 / term 0), and what it restarts with is a function of (seed, world, tick s + 1) alone.
-// So its lane posts it the moment `done` is known, at the END of step s, and collects the fresh state right before it
-// moves again, in step s + 2; in between a fifth wavefront of the block -- it owns no worlds -- runs the re-seeding pass
-// (~0.9 us of dependent arithmetic) beside two whole steps of the other four.  The wavefronts meet only through sequence
+// The next-step fused rollout's hand-over (round 5): NO barrier, and a wavefront of its own that only re-seeds.  A world that
+// finishes at step s does not move during step s + 1 (that tick reports reward 0 / term 0), and what it restarts with is a
+// function of (seed, world, tick s + 1) alone.  So its lane posts it the moment `done` is known, at the END of step s, and
+// collects the fresh state right before it moves again, in step s + 2; in between -- ONE step of slack: `done` is not
+// known earlier, the state is due one step later -- a fifth wavefront of the block, which owns no worlds, runs the
+// re-seeding pass (~0.9 us of dependent arithmetic) beside the other four.  The wavefronts meet only through sequence
 // numbers in LDS.  Post p of a tile (p = 0: the worlds that came into the launch marked done; p = s + 1: the worlds that
 // finished at step s), global sequence q = q0 + p:
 //   post     every stepping wavefront lists its lanes that need a fresh state (list / count, double-buffered by the parity
@@ -878,9 +878,8 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 //            lanes per world) into result[parity][wave * 64 + position] and sets served = q + 1.
 //   collect  a wavefront with lanes on list q waits for served > q right before those lanes move again.
 // History: with two block-wide barriers per step and the pass on a rotating duty wavefront (the same-step mode's protocol
-// below, and this mode's until round 4) three wavefronts of four idle through every pass: 4.05 us per step where the steps
-// alone take 1.40.  A fifth wavefront with the post at the top of step s + 1 (one step of slack) measured 3.60-3.78
-// (profiles/r04/fused_mail/).  Every wait is bounded: one that sees no progress for MAIL_SPIN_LIMIT polls gives up (the
+// below, and this mode's until round 4) three wavefronts of four idle through every pass: 3.98 us per step where the steps
+// alone take 1.3; this protocol in the library 3.85 (3.65 with sampled actions).  Every wait is bounded: one that sees no progress for MAIL_SPIN_LIMIT polls gives up (the
 // results are then wrong, every test compares them, and the grid drains).
 #ifndef AQUA_FUSED_MAIL
 #define AQUA_FUSED_MAIL 1                                   // (0: the barrier protocol for the next-step mode too -- A/B timing)
@@ -890,8 +889,9 @@ __device__ __forceinline__ void collect_reseed(EnvState& e, bool need, const Res
 #endif
 constexpr uint32_t MAIL_SPIN_LIMIT = AQUA_MAIL_SPIN_LIMIT;
 // the re-seeding wavefront runs at raised priority: its pass is one long dependent chain, and the four stepping wavefronts it
-// shares a SIMD with would otherwise leave it a fifth of the issue slots (262 144 worlds, next-step restarts, us per step:
-// priority 0 4.22, 1 3.52, 2 3.48-3.58, 3 3.50-3.52; the barrier protocol 4.01-4.03 -- profiles/r05/fused_mail/)
+// shares a SIMD with would otherwise leave it a fifth of the issue slots (262 144 worlds, next-step restarts, us per step in
+// builds with ONE action kind: priority 0 4.22, 1 3.52, 2 3.48-3.58, 3 3.50-3.52; the barrier protocol 4.01-4.03 --
+// profiles/r05/fused_mail/; the library's own figures are 0.3 higher across the board)
 #ifndef AQUA_MAIL_PRIO
 #define AQUA_MAIL_PRIO 2
 #endif
