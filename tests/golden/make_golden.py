@@ -22,6 +22,11 @@ from ``np.random.RandomState(s)`` to store them as ``noise_u = draw / sigma`` in
 values before every recorded step (teacher forcing), so a float32 device
 implementation can start from bit-identical inputs.
 
+Files: step_golden.npz (teacher-forced rows), traj_golden.npz (five free-running 260-step trajectories), reset_golden.npz
+(reset samples), policy_golden.npz (bearing-policy statistics), dqn_policies.npz (the reference's trained weights and
+published results as numbers), episodes_golden.npz (round 5: whole episodes of the evaluation loop, back to back, with
+the reset states the reference produced; random streams of its own, written last -- the older files regenerate bit for bit).
+
 Usage:  python tests/golden/make_golden.py [--time]
 """
 import argparse
